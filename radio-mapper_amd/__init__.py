@@ -1,0 +1,9 @@
+"""MI355X-native TDoA cross-correlation engine (drop-in behind tdoa_processor.py's API).
+
+  synth           synthetic IQ windows of the BASELINE shapes (numpy)
+  xcorr           ctypes binding of the C-ABI library  include/rmx.h  (HIP, gfx950)
+  tdoa_processor  host-side mirror of the reference's tdoa_processor.py interface
+"""
+from . import synth  # noqa: F401
+
+__all__ = ["synth"]

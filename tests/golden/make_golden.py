@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""Generates the golden fixtures in this directory FROM THE REFERENCE MODULE ITSELF.
+
+Run in the build container only (``/root/reference`` does not exist on the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+It imports ``/root/reference/tdoa_processor.py`` and records
+
+* ``xcorr_*.npz``  -- outputs of ``tdoa_processor.correlate`` (the module's only xcorr symbol,
+  ``tdoa_processor.py:20``; it *is* ``scipy.signal.correlate``) called as
+  ``correlate(x_j, x_i, mode='full', method='fft')`` for every pair i<j in the reference's loop
+  order (``tdoa_processor.py:156-157``), reduced by the path's spec (SURVEY.md §8a-spec S4-S6:
+  ``np.abs`` -> ``np.argmax`` -> 3-point parabola).  Small cases store their inputs (as the raw
+  uint8 I/Q that decodes to them); large cases store the generator seed + an input checksum.
+* ``tdoa_conventions.json`` -- ``TDoACalculator.calculate_tdoa_measurements`` on the hand-built
+  detections of the reference's own ``main()`` example (``tdoa_processor.py:475-490``): pins the
+  pair order, the sign (buoy2 - buoy1) and the ns -> metres conversion.
+
+Only arrays / JSON are written: no reference source text.
+"""
+import hashlib
+import importlib.util
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+import radio_mapper_amd as rm  # noqa: E402  (synthetic inputs only)
+
+
+def load_reference():
+    spec = importlib.util.spec_from_file_location("ref_tdoa_processor",
+                                                  "/root/reference/tdoa_processor.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def reduce_full(c, n):
+    m = np.abs(c)
+    k = int(np.argmax(m))
+    if 0 < k < m.shape[0] - 1:
+        a, b, cc = float(m[k - 1]), float(m[k]), float(m[k + 1])
+        den = a - 2.0 * b + cc
+        frac = 0.0 if den == 0.0 else 0.5 * (a - cc) / den
+    else:
+        frac = 0.0
+    mm = m.astype(np.float64).copy()
+    top = mm[k]
+    mm[k] = -1.0
+    margin = (top - mm.max()) / top if top > 0 else 0.0
+    taps = [float(m[max(k - 1, 0)]), float(m[k]), float(m[min(k + 1, m.shape[0] - 1)])]
+    return k - (n - 1), frac, float(m[k]), margin, taps
+
+
+def run_case(ref, iq):
+    W, B, N = iq.shape
+    pairs = [(i, j) for i in range(B) for j in range(i + 1, B)]
+    P = len(pairs)
+    lag_int = np.zeros((W, P), np.int32)
+    lag_frac = np.zeros((W, P), np.float64)
+    peak = np.zeros((W, P), np.float32)
+    margin = np.zeros((W, P), np.float64)
+    taps = np.zeros((W, P, 3), np.float32)
+    for w in range(W):
+        for q, (i, j) in enumerate(pairs):
+            c = ref.correlate(iq[w, j], iq[w, i], mode="full", method="fft")
+            assert c.dtype == np.complex64 and c.shape[0] == 2 * N - 1
+            lag_int[w, q], lag_frac[w, q], peak[w, q], margin[w, q], taps[w, q] = reduce_full(c, N)
+    return dict(pairs=np.array(pairs, np.int32), lag_int=lag_int, lag_frac=lag_frac, peak=peak,
+                margin=margin, taps=taps)
+
+
+def checksum(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def main():
+    ref = load_reference()
+    import scipy
+    meta = dict(numpy=np.__version__, scipy=scipy.__version__,
+                primitive="tdoa_processor.correlate(x_j, x_i, mode='full', method='fft')")
+
+    small = [
+        ("xcorr_b3_n1024", dict(n_windows=2, n_buoys=3, n_samples=1024, sample_rate_hz=2.4e6, seed=11)),
+        ("xcorr_b3_n4096", dict(n_windows=1, n_buoys=3, n_samples=4096, sample_rate_hz=2.4e6, seed=12)),
+        ("xcorr_b8_n4096", dict(n_windows=4, n_buoys=8, n_samples=4096, sample_rate_hz=10e6, seed=1003)),
+        ("xcorr_b4_n256", dict(n_windows=3, n_buoys=4, n_samples=256, sample_rate_hz=2.048e6, seed=13)),
+        ("xcorr_b3_n16384", dict(n_windows=1, n_buoys=3, n_samples=16384, sample_rate_hz=2.048e6, seed=14)),
+    ]
+    for name, kw in small:
+        iq, delays, raw = rm.synth.make_windows(return_u8=True, **kw)
+        res = run_case(ref, iq)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), raw_u8=raw, delays=delays,
+                            sample_rate_hz=kw["sample_rate_hz"], **res)
+        print(name, "min margin %.3e" % res["margin"].min())
+
+    # edge cases with stored complex inputs (ties, zeros, impulses, edge peaks)
+    N = 256
+    e = np.zeros((6, 2, N), np.complex64)
+    # w0: all zeros -> every magnitude ties at 0 -> argmax = index 0 -> lag -(N-1), frac 0
+    # w1: impulses: x_i = delta[5], x_j = delta[25] -> lag +20
+    e[1, 0, 5] = 1.0; e[1, 1, 25] = 2.0 - 1.0j
+    # w2: peak at the most positive lag N-1 (edge, frac 0): x_i = delta[0], x_j = delta[N-1]
+    e[2, 0, 0] = 3.0; e[2, 1, N - 1] = 1.0j
+    # w3: peak at the most negative lag -(N-1)
+    e[3, 0, N - 1] = 1.0; e[3, 1, 0] = -2.0
+    # w4: two equal peaks (lags -7 and +9): ties -> most negative lag
+    e[4, 0, 100] = 1.0; e[4, 1, 93] = 1.0; e[4, 1, 109] = 1.0
+    # w5: constant inputs -> triangular magnitude, peak at lag 0
+    e[5, 0, :] = 4.5 - 2.5j; e[5, 1, :] = -1.5 + 0.5j
+    res = run_case(ref, e)
+    np.savez_compressed(os.path.join(HERE, "xcorr_edge_n256.npz"), iq=e, **res)
+    print("edge lags", res["lag_int"].ravel(), res["lag_frac"].ravel())
+
+    # large, seed-regenerated cases (inputs not stored)
+    large = [
+        ("xcorr_cfg1_n262144", dict(n_windows=1, n_buoys=3, n_samples=262144, sample_rate_hz=2.4e6, seed=1001)),
+        ("xcorr_b3_n1048576", dict(n_windows=1, n_buoys=3, n_samples=1048576, sample_rate_hz=2.4e6, seed=1002)),
+    ]
+    for name, kw in large:
+        iq, delays = rm.synth.make_windows(**kw)
+        res = run_case(ref, iq)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), delays=delays,
+                            gen=json.dumps(kw), input_sha256=checksum(iq), **res)
+        print(name, "min margin %.3e" % res["margin"].min(), res["lag_int"].ravel())
+
+    # conventions of the pair loop (tdoa_processor.py:146-198) on main()'s example
+    proc = ref.TDoAProcessor()
+    buoys = [("BUOY_ALPHA", 51.505, -0.09, 0.0, 50000), ("BUOY_BETA", 51.51, -0.1, 0.0, 75000),
+             ("BUOY_GAMMA", 51.5, -0.12, 0.0, 60000)]
+    for b in buoys:
+        proc.register_buoy(ref.BuoyPosition(*b))
+    base = 1_700_000_000_000_000_000
+    dets = [("BUOY_ALPHA", 121.5, -55, "2025-01-18T16:30:00Z", base, 51.505, -0.09, 0.9, "emergency"),
+            ("BUOY_BETA", 121.5, -60, "2025-01-18T16:30:00Z", base + 150000, 51.51, -0.1, 0.85, "emergency"),
+            ("BUOY_GAMMA", 121.5, -58, "2025-01-18T16:30:00Z", base + 300000, 51.5, -0.12, 0.88, "emergency")]
+    meas = proc.tdoa_calculator.calculate_tdoa_measurements(
+        [ref.SignalDetection(*d) for d in dets], proc.buoy_positions)
+    conv = dict(meta=meta, buoys=buoys, detections=dets,
+                measurements=[dict(buoy1_id=m.buoy1_id, buoy2_id=m.buoy2_id,
+                                   time_difference_ns=m.time_difference_ns,
+                                   distance_difference_m=m.distance_difference_m,
+                                   confidence=m.confidence, frequency_mhz=m.frequency_mhz)
+                              for m in meas],
+                network_status=proc.get_buoy_network_status(),
+                freq_groups={str(k): [d.buoy_id for d in v] for k, v in proc._group_by_frequency(
+                    [ref.SignalDetection(*d) for d in dets] +
+                    [ref.SignalDetection("BUOY_ALPHA", 121.505, -50, "t", base, 0, 0, 0.5),
+                     ref.SignalDetection("BUOY_BETA", 156.8, -50, "t", base, 0, 0, 0.5)]).items()},
+                time_window=[d.buoy_id for d in proc._filter_by_time_window(
+                    [ref.SignalDetection("A", 1.0, 0, "t", base, 0, 0, 1.0),
+                     ref.SignalDetection("B", 1.0, 0, "t", base - 9_000_000_000, 0, 0, 1.0),
+                     ref.SignalDetection("C", 1.0, 0, "t", base - 11_000_000_000, 0, 0, 1.0)])])
+    with open(os.path.join(HERE, "tdoa_conventions.json"), "w") as f:
+        json.dump(conv, f, indent=1)
+    print("conventions:", [(m["buoy1_id"], m["buoy2_id"], m["time_difference_ns"]) for m in conv["measurements"]])
+
+
+if __name__ == "__main__":
+    main()
