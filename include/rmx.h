@@ -1,0 +1,111 @@
+/* rmx.h -- C ABI of the MI355X (gfx950) TDoA cross-correlation engine.
+ *
+ * What this boundary replaces in the reference (physiii/radio-mapper):
+ *   The reference has no FFI for this path: the path sits behind plain
+ *   Python methods of tdoa_processor.py.  The seam is the body of the pair loop of
+ *   TDoACalculator.calculate_tdoa_measurements (tdoa_processor.py:156-193), whose time difference
+ *   `time_diff_ns = det2.gps_timestamp_ns - det1.gps_timestamp_ns` (tdoa_processor.py:166) is
+ *   replaced by a lag measured from IQ with the cross-correlation primitive the module imports
+ *   (`from scipy.signal import correlate`, tdoa_processor.py:20).  rmx_xcorr_batch() is that
+ *   primitive, batched over capture windows x buoy pairs:
+ *
+ *     for every window w, for every pair (i, j), i < j, in the reference's nested-loop order
+ *     (tdoa_processor.py:156-157):
+ *         c   = correlate(x[w][j], x[w][i], mode='full', method='fft')   (complex64, 2N-1 lags)
+ *         m   = |c|                                                     (float32)
+ *         k   = argmax m   (ties -> lowest k)        lag_int  = k - (N-1)
+ *         d   = 3-point parabolic vertex offset      lag_frac = d  (0 at the edges / flat top)
+ *         peak = m[k]
+ *     lag = lag_int + lag_frac samples = delay(buoy j) - delay(buoy i)   (sign of
+ *     TDoAMeasurement.time_difference_ns: buoy2 - buoy1, tdoa_processor.py:51).
+ *
+ *   The ctypes binding a maintainer adds on the reference side is shown in INTEGRATION.md.
+ *
+ * Conventions: plain pointers and sizes, no torch / numpy types.  The caller owns every buffer it
+ * passes; the library owns only ctx-internal device scratch.  Functions return 0 (RMX_OK) or a
+ * negative code and never abort; rmx_last_error() gives the text.  A ctx is single-owner (not
+ * thread safe); use one ctx per device (one process per GPU, or one host thread per ctx).
+ */
+#ifndef RMX_H
+#define RMX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rmx_ctx rmx_ctx;
+
+enum {
+    RMX_OK = 0,
+    RMX_E_INVAL = -1,       /* bad argument */
+    RMX_E_NODEV = -2,       /* no usable HIP device */
+    RMX_E_HIP = -3,         /* a HIP runtime call failed (text in rmx_last_error) */
+    RMX_E_NOMEM = -4,       /* device or host allocation failed */
+    RMX_E_UNSUPPORTED = -5  /* shape not supported by this build */
+};
+
+/* flags of rmx_xcorr_batch() */
+enum {
+    RMX_IN_DEVICE = 1u,   /* `iq` is a device pointer (already resident in HBM) */
+    RMX_OUT_DEVICE = 2u,  /* lag_int / lag_frac / peak are device pointers; the call is then
+                             asynchronous on the ctx stream (rmx_synchronize to wait) */
+    RMX_IN_U8 = 4u        /* `iq` is raw rtl_sdr uint8 I,Q interleaved [W][B][N][2]; decoded in
+                             the first kernel as (float)u8 - 127.5f (buoy_node.py:392-398) */
+};
+
+#define RMX_VERSION 1
+
+int rmx_version(void);
+
+/* Number of HIP devices visible, 0 if none / no driver.  Never fails. */
+int rmx_device_count(void);
+
+/* Create an engine for windows of `n_samples` complex64 samples from `n_buoys` buoys.
+ * n_samples: power of two, 16 .. 4194304.  max_windows: largest n_windows a later call may pass.
+ * flags: reserved, pass 0. */
+int rmx_create(rmx_ctx** out, int device_id, int n_buoys, int n_samples, int max_windows,
+               unsigned flags);
+void rmx_destroy(rmx_ctx* ctx);
+
+/* Text of the last error on this ctx (or of the last failed rmx_create when ctx == NULL). */
+const char* rmx_last_error(const rmx_ctx* ctx);
+
+/* Use an existing hipStream_t (e.g. torch's current stream) for all work of this ctx. */
+int rmx_set_stream(rmx_ctx* ctx, void* hip_stream);
+
+/* Tuning knobs (all optional): "chunk_windows" (windows per forward/pair launch pair),
+ * "pairs_per_block", "timing" (1: bracket every launch with HIP events).  Returns RMX_E_INVAL for
+ * an unknown key. */
+int rmx_set_option(rmx_ctx* ctx, const char* key, long value);
+
+/* The hot path.
+ *   iq        complex64 interleaved I,Q  [n_windows][n_buoys][n_samples][2] float32, row-major
+ *             (or uint8 with RMX_IN_U8); host pointer unless RMX_IN_DEVICE.
+ *   pairs     int32 [n_pairs][2] = (i, j) buoy indices, or NULL for all i<j in nested-loop order
+ *             (then n_pairs must be n_buoys*(n_buoys-1)/2 or 0).  Host pointer always.
+ *   lag_int   int32   [n_windows][n_pairs]
+ *   lag_frac  float32 [n_windows][n_pairs]   sub-sample offset in [-0.5, 0.5]
+ *   peak      float32 [n_windows][n_pairs]   |c| at the integer peak (scipy scaling)
+ */
+int rmx_xcorr_batch(rmx_ctx* ctx, const void* iq, int n_windows, const int32_t* pairs, int n_pairs,
+                    int32_t* lag_int, float* lag_frac, float* peak, unsigned flags);
+
+/* Wait for all work queued on the ctx stream. */
+int rmx_synchronize(rmx_ctx* ctx);
+
+/* With option "timing"=1: accumulated HIP-event times of the last rmx_xcorr_batch call, per kernel
+ * family (forward-spectrum kernels, pair kernels), and the number of launches of each.  Waits for
+ * the stream.  Any pointer may be NULL. */
+int rmx_last_timing(rmx_ctx* ctx, float* fwd_ms, int* fwd_launches, float* pair_ms,
+                    int* pair_launches);
+
+/* Bytes of device scratch the ctx holds (spectra, tables, staging). */
+size_t rmx_scratch_bytes(const rmx_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RMX_H */

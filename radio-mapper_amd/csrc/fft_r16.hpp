@@ -1,0 +1,195 @@
+// fft_r16.hpp -- register-resident radix-16 building blocks for the LDS-resident xcorr kernels.
+//
+// Work decomposition for one length-L = 2M transform, M = 4096 = 16^3 (gfx950, wave64):
+//   * the L-point transform is split by bin parity into two M-point transforms (bins 2k and 2k+1);
+//     for a window zero-padded from N = M to L = 2M samples that first radix-2 stage is free:
+//         X[2k]   = FFT_M(x[n])            X[2k+1] = FFT_M(x[n] * W_L^n)
+//   * 512 threads; thread t = 2u + p holds 16 complex points of sub-transform p (the parity sits on
+//     lane bit 0, so that the last radix-2 stage of the inverse is one DPP quad_perm exchange);
+//   * three radix-16 passes in registers, two exchanges through LDS between them:
+//         role A  u = 16*n1 + n0   slots n2 / k0      (time side)
+//         role B  u = 16*k0 + n0   slots n1 / k1
+//         role C  u = 16*k0 + k1   slots n0 / k2      (frequency side; bin = 2(k0+16k1+256k2)+p)
+//     exchange A<->B crosses waves (workgroup barrier); exchange B<->C stays inside one 32-lane
+//     half wave (fixed k0), so it needs no barrier, only the wave's own LDS ordering.
+//   * the inverse is the same forward blocks in reverse order applied to (im, re)-swapped data:
+//     swap o F o swap = conj(F) for every linear block, and |.| does not see the final swap.
+// All LDS images are bank-conflict free for ds_write_b64 / ds_read_b64 (see the index functions).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace rmx {
+
+constexpr int kM = 4096;       // sub-transform length (= window length N of the LDS path)
+constexpr int kL = 2 * kM;     // zero-padded transform length
+constexpr int kThreads = 512;  // threads per workgroup
+constexpr int kSlots = 16;     // complex points per thread
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+
+// 4-point DFT (W4 = -i), natural order in and out, in place.
+__device__ __forceinline__ void dft4(float2& a0, float2& a1, float2& a2, float2& a3) {
+    const float2 t0 = cadd(a0, a2), t1 = csub(a0, a2);
+    const float2 t2 = cadd(a1, a3), t3 = csub(a1, a3);
+    a0 = cadd(t0, t2);
+    a2 = csub(t0, t2);
+    a1 = make_float2(t1.x + t3.y, t1.y - t3.x);  // t1 - i*t3
+    a3 = make_float2(t1.x - t3.y, t1.y + t3.x);  // t1 + i*t3
+}
+
+// W16^e for the inner twiddles of the 16-point DFT (e = q0*ka, q0, ka in 0..3).
+#define RMX_C1 0.92387953251128675613f  /* cos(pi/8) */
+#define RMX_S1 0.38268343236508977173f  /* sin(pi/8) */
+#define RMX_RH 0.70710678118654752440f   /* sqrt(1/2) */
+
+template <int E>
+__device__ __forceinline__ float2 mul_w16(float2 a) {
+    if constexpr (E == 0) return a;
+    else if constexpr (E == 1) return cmul(a, make_float2(RMX_C1, -RMX_S1));
+    else if constexpr (E == 2) return make_float2((a.x + a.y) * RMX_RH, (a.y - a.x) * RMX_RH);
+    else if constexpr (E == 3) return cmul(a, make_float2(RMX_S1, -RMX_C1));
+    else if constexpr (E == 4) return make_float2(a.y, -a.x);
+    else if constexpr (E == 6) return make_float2((a.y - a.x) * RMX_RH, -(a.x + a.y) * RMX_RH);
+    else if constexpr (E == 9) return cmul(a, make_float2(-RMX_C1, RMX_S1));
+    else return a;
+}
+
+// 16-point DFT, X[k] = sum_q v[q] W16^(qk), natural order in, natural order out.
+__device__ __forceinline__ void dft16(float2 (&v)[16]) {
+    // q = 4*q1 + q0, k = ka + 4*kb.  Step 1: DFT4 over q1 for each q0 -> y[q0][ka] in v[q0+4ka].
+    dft4(v[0], v[4], v[8], v[12]);
+    dft4(v[1], v[5], v[9], v[13]);
+    dft4(v[2], v[6], v[10], v[14]);
+    dft4(v[3], v[7], v[11], v[15]);
+    // Step 2: y[q0][ka] *= W16^(q0*ka)
+    v[5] = mul_w16<1>(v[5]);   v[6] = mul_w16<2>(v[6]);    v[7] = mul_w16<3>(v[7]);
+    v[9] = mul_w16<2>(v[9]);   v[10] = mul_w16<4>(v[10]);  v[11] = mul_w16<6>(v[11]);
+    v[13] = mul_w16<3>(v[13]); v[14] = mul_w16<6>(v[14]);  v[15] = mul_w16<9>(v[15]);
+    // Step 3: DFT4 over q0 for each ka -> X[ka + 4kb] lands in v[4ka + kb]
+    dft4(v[0], v[1], v[2], v[3]);
+    dft4(v[4], v[5], v[6], v[7]);
+    dft4(v[8], v[9], v[10], v[11]);
+    dft4(v[12], v[13], v[14], v[15]);
+    // un-transpose (pure register renaming)
+    float2 t;
+    t = v[1];  v[1] = v[4];   v[4] = t;
+    t = v[2];  v[2] = v[8];   v[8] = t;
+    t = v[3];  v[3] = v[12];  v[12] = t;
+    t = v[6];  v[6] = v[9];   v[9] = t;
+    t = v[7];  v[7] = v[13];  v[13] = t;
+    t = v[11]; v[11] = v[14]; v[14] = t;
+}
+
+// W32^q, q = 0..15 (exp(-2*pi*i*q/32)): the per-slot part of the odd sub-transform's W_L^n.
+__device__ __forceinline__ float2 w32(int q) {
+    constexpr float c[16] = {1.0f, 0.98078528040323044913f, 0.92387953251128675613f,
+                             0.83146961230254523708f, 0.70710678118654752440f,
+                             0.55557023301960222474f, 0.38268343236508977173f,
+                             0.19509032201612826785f, 0.0f, -0.19509032201612826785f,
+                             -0.38268343236508977173f, -0.55557023301960222474f,
+                             -0.70710678118654752440f, -0.83146961230254523708f,
+                             -0.92387953251128675613f, -0.98078528040323044913f};
+    constexpr float s[16] = {0.0f, 0.19509032201612826785f, 0.38268343236508977173f,
+                             0.55557023301960222474f, 0.70710678118654752440f,
+                             0.83146961230254523708f, 0.92387953251128675613f,
+                             0.98078528040323044913f, 1.0f, 0.98078528040323044913f,
+                             0.92387953251128675613f, 0.83146961230254523708f,
+                             0.70710678118654752440f, 0.55557023301960222474f,
+                             0.38268343236508977173f, 0.19509032201612826785f};
+    return make_float2(c[q], -s[q]);
+}
+
+// ---- LDS exchanges (complex index into a float2 array of kL entries) -------------------------
+// A<->B image: idx = k0*512 + ((n1*16 + n0)*2 + p).  Role-A lanes are contiguous in it for a fixed
+// slot k0; role-B lanes (k0 lowbit, n0, p within a wave) read one contiguous 256-B run per 32-lane
+// half for a fixed slot n1: conflict free both ways.
+__device__ __forceinline__ void wave_lds_fence() {
+    // orders this wave's LDS writes before its later LDS reads (same-wave exchange, no barrier)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ void xchg_a_write(float2* lds, const float2 (&v)[16], int t) {
+#pragma unroll
+    for (int k0 = 0; k0 < 16; ++k0) lds[k0 * 512 + t] = v[k0];
+}
+__device__ __forceinline__ void xchg_a_read(const float2* lds, float2 (&v)[16], int t) {
+#pragma unroll
+    for (int k0 = 0; k0 < 16; ++k0) v[k0] = lds[k0 * 512 + t];
+}
+// role B thread: u = 16*k0 + n0; slot = n1
+__device__ __forceinline__ void xchg_b_write(float2* lds, const float2 (&v)[16], int t) {
+    const int p = t & 1, u = t >> 1, k0 = u >> 4, n0 = u & 15;
+    const int base = k0 * 512 + n0 * 2 + p;
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) lds[base + n1 * 32] = v[n1];
+}
+__device__ __forceinline__ void xchg_b_read(const float2* lds, float2 (&v)[16], int t) {
+    const int p = t & 1, u = t >> 1, k0 = u >> 4, n0 = u & 15;
+    const int base = k0 * 512 + n0 * 2 + p;
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) v[n1] = lds[base + n1 * 32];
+}
+// B<->C image (inside one half wave, fixed k0): idx = k0*kBcHalf + k1*kBcRow + 2*n0 + p with rows of
+// 32 complex padded to 34.  Role B (a = n0, slot k1) touches 32 contiguous complex per access; role
+// C (a = k1, slot n0) touches 16 rows 34 complex apart, i.e. 16 distinct 16-B bank groups (68*a mod
+// 64 = 4*a): conflict free both ways, and every slot is base + immediate offset (no per-slot
+// address registers).
+constexpr int kBcRow = 34;
+constexpr int kBcHalf = 16 * kBcRow;          // complex per half wave
+constexpr int kXchgF2 = 16 * kBcHalf;         // complex in the whole exchange image (>= kL)
+__device__ __forceinline__ void xchg_bc_write_b(float2* lds, const float2 (&v)[16], int t) {
+    const int p = t & 1, u = t >> 1, k0 = u >> 4, a = u & 15;
+    float2* base = lds + k0 * kBcHalf + 2 * a + p;
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) base[k1 * kBcRow] = v[k1];
+}
+__device__ __forceinline__ void xchg_bc_read_c(const float2* lds, float2 (&v)[16], int t) {
+    const int p = t & 1, u = t >> 1, k0 = u >> 4, a = u & 15;
+    const float2* base = lds + k0 * kBcHalf + a * kBcRow + p;
+#pragma unroll
+    for (int n0 = 0; n0 < 16; ++n0) v[n0] = base[2 * n0];
+}
+__device__ __forceinline__ void xchg_bc_write_c(float2* lds, const float2 (&v)[16], int t) {
+    const int p = t & 1, u = t >> 1, k0 = u >> 4, a = u & 15;
+    float2* base = lds + k0 * kBcHalf + a * kBcRow + p;
+#pragma unroll
+    for (int n0 = 0; n0 < 16; ++n0) base[2 * n0] = v[n0];
+}
+__device__ __forceinline__ void xchg_bc_read_b(const float2* lds, float2 (&v)[16], int t) {
+    const int p = t & 1, u = t >> 1, k0 = u >> 4, a = u & 15;
+    const float2* base = lds + k0 * kBcHalf + 2 * a + p;
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) v[k1] = base[k1 * kBcRow];
+}
+
+// TW2[a][b] = W_256^(a*b) lives in LDS as 16 rows of 16 complex padded to 18 (144-B rows: the 16
+// rows then start on 16 distinct 16-B bank groups, so a ds_read_b128 of one column is conflict free).
+constexpr int kTw2RowF2 = 18;
+__device__ __forceinline__ void mul_tw2(float2 (&v)[16], const float2* tw2_lds, int a) {
+    const float4* row = reinterpret_cast<const float4*>(tw2_lds + a * kTw2RowF2);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float4 w = row[j];
+        if (j > 0) v[2 * j] = cmul(v[2 * j], make_float2(w.x, w.y));
+        v[2 * j + 1] = cmul(v[2 * j + 1], make_float2(w.z, w.w));
+    }
+}
+
+__device__ __forceinline__ void mul_tw1(float2 (&v)[16], const float2 (&tw1)[16]) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = cmul(v[k], tw1[k]);
+}
+
+// lane <-> lane^1 exchange (DPP quad_perm [1,0,3,2]); folds into the consuming VOP2 as a DPP operand
+__device__ __forceinline__ float dpp_xor1(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));
+}
+
+}  // namespace rmx

@@ -1,0 +1,677 @@
+// rmx_hip.hip -- gfx950 kernels and the C ABI (include/rmx.h) of the TDoA cross-correlation engine.
+//
+// Path (conventions of tdoa_processor.py:20,51,156-157,166-170):
+//   per window w, pair (i<j):  r = IFFT_L( FFT_L(x_j) * conj(FFT_L(x_i)) ), L = 2N (zero padded)
+//                               m = |r|, k = argmax over the 2N-1 'full' lags, parabolic offset.
+// Two kernel families, launched back to back per chunk of windows on one stream:
+//   k_fwd   one workgroup per (window, buoy): forward spectrum -> HBM/L2 scratch, stored in the
+//           *register layout* of the pair kernel (every thread later reads back exactly the 16
+//           bins it wrote: 16-B-per-lane coalesced both ways, no reordering pass);
+//   k_pair  one workgroup per (window, group of pairs): loads the two spectra, multiplies in
+//           registers, inverse transform (3 radix-16 passes, 2 LDS exchanges), |.|^2, workgroup
+//           argmax with numpy tie-breaking, 3-tap parabola, 12 bytes out per pair-window.
+// No MFMA (not a contraction), no library FFT: everything below is hand written for wave64 / LDS.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/rmx.h"
+#include "fft_r16.hpp"
+
+namespace rmx {
+
+struct PairItem {
+    int i, j, out, pad;
+};
+
+// LDS carve (bytes) of both kernels: exchange image, TW2 table, reduction words
+constexpr int kLdsXchg = kXchgF2 * 8;                  // 69632
+constexpr int kLdsTw2 = 16 * kTw2RowF2 * 8;            // 2304
+constexpr int kLdsRed = 64;
+constexpr int kLdsBytes = kLdsXchg + kLdsTw2 + kLdsRed;
+
+__device__ __forceinline__ void load_tw2_to_lds(float2* tw2_lds, const float2* __restrict__ tw2_g, int t) {
+    // tw2_g: [16][16] complex; LDS rows padded to kTw2RowF2
+    if (t < 256) tw2_lds[(t >> 4) * kTw2RowF2 + (t & 15)] = tw2_g[t];
+}
+
+__device__ __forceinline__ void load_tw1(float2 (&tw1)[16], const float4* __restrict__ tw1_g, int t) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float4 w = tw1_g[j * kThreads + t];
+        tw1[2 * j] = make_float2(w.x, w.y);
+        tw1[2 * j + 1] = make_float2(w.z, w.w);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Forward spectra.  grid = n_items workgroups of 512; item = wl * B + b inside the chunk.
+//   spec layout: [item][j = 0..7][t = 0..511] float4 = bins of slots (2j, 2j+1) of thread t,
+//   scaled by `scale` (a power of two; the pair kernel's product then carries 1/L exactly).
+template <bool U8>
+__global__ __launch_bounds__(kThreads, 4) void k_fwd(const void* __restrict__ iq_v, float4* __restrict__ spec,
+                                                     const float4* __restrict__ tw1_g,
+                                                     const float2* __restrict__ tw2_g, long first_item,
+                                                     float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2* xl = reinterpret_cast<float2*>(smem);
+    float2* tw2_lds = reinterpret_cast<float2*>(smem + kLdsXchg);
+    const int t = threadIdx.x;
+    const int p = t & 1, u = t >> 1;
+    const long item = first_item + blockIdx.x;
+
+    load_tw2_to_lds(tw2_lds, tw2_g, t);
+    float2 tw1[16];
+    load_tw1(tw1, tw1_g, t);
+
+    float2 v[16];
+    if constexpr (U8) {
+        const uchar2* x = reinterpret_cast<const uchar2*>(iq_v) + item * kM;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const uchar2 b = x[q * 256 + u];
+            v[q] = make_float2((float)b.x - 127.5f, (float)b.y - 127.5f);
+        }
+    } else {
+        const float2* x = reinterpret_cast<const float2*>(iq_v) + item * kM;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = x[q * 256 + u];
+    }
+    // odd sub-transform: x[n] * W_L^n = x * W32^q * W_L^u ; W_L^u is folded into tw1 (odd lanes)
+    if (p) {
+#pragma unroll
+        for (int q = 1; q < 16; ++q) v[q] = cmul(v[q], w32(q));
+    }
+    dft16(v);        // n2 -> k0
+    mul_tw1(v, tw1); // W_M^(u*k0) [* W_L^u on odd lanes]
+    xchg_a_write(xl, v, t);
+    __syncthreads();
+    xchg_b_read(xl, v, t);
+    dft16(v);                         // n1 -> k1
+    mul_tw2(v, tw2_lds, u & 15);      // W_256^(n0*k1)
+    __syncthreads();                  // every wave is done reading the A<->B image
+    xchg_bc_write_b(xl, v, t);
+    wave_lds_fence();
+    xchg_bc_read_c(xl, v, t);
+    dft16(v);                         // n0 -> k2
+    float4* out = spec + (long)blockIdx.x * (8 * kThreads);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        out[j * kThreads + t] = make_float4(v[2 * j].x * scale, v[2 * j].y * scale,
+                                            v[2 * j + 1].x * scale, v[2 * j + 1].y * scale);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pair kernel.  grid = n_windows_in_chunk * n_parts; each workgroup walks items[part_begin..end).
+//   out arrays are indexed [(first_window + wl) * n_pairs + item.out].
+__global__ __launch_bounds__(kThreads, 4) void k_pair(const float4* __restrict__ spec,
+                                                      const float4* __restrict__ tw1_g,
+                                                      const float2* __restrict__ tw2_g,
+                                                      const PairItem* __restrict__ items,
+                                                      const int* __restrict__ part_begin, int n_parts,
+                                                      int n_buoys, int n_pairs, int n_win, int xcd_map,
+                                                      long first_window, float out_scale,
+                                                      int* __restrict__ lag_int, float* __restrict__ lag_frac,
+                                                      float* __restrict__ peak) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2* xl = reinterpret_cast<float2*>(smem);
+    float2* tw2_lds = reinterpret_cast<float2*>(smem + kLdsXchg);
+    float* red_max = reinterpret_cast<float*>(smem + kLdsXchg + kLdsTw2);      // [8]
+    int* red_k = reinterpret_cast<int*>(smem + kLdsXchg + kLdsTw2 + 32);       // [1]
+    float* red_tap = reinterpret_cast<float*>(smem + kLdsXchg + kLdsTw2 + 48); // [3]
+
+    const int t = threadIdx.x;
+    const int p = t & 1, u = t >> 1;
+    const int lane = t & 63, wave = t >> 6;
+
+    // blockIdx -> (window, part).  Workgroups of one window share its spectra through the XCD's
+    // L2, so keep them on one XCD (blocks b and b+8 share an XCD) and adjacent in dispatch order.
+    // Placement only changes speed, never results.
+    int wl, part;
+    {
+        const int b = blockIdx.x;
+        if (xcd_map) {
+            const int xcd = b & 7, s = b >> 3;
+            wl = (s / n_parts) * 8 + xcd;
+            part = s % n_parts;
+        } else {
+            wl = b / n_parts;
+            part = b % n_parts;
+        }
+    }
+    (void)n_win;
+
+    load_tw2_to_lds(tw2_lds, tw2_g, t);
+    __syncthreads();
+
+    const float sgn = p ? -1.0f : 1.0f;
+    const int it_begin = part_begin[part];
+    const int it_end = part_begin[part + 1];
+    const long wbase = (long)wl * n_buoys;
+    // software pipeline: the spectra of pair it+1 are requested while pair it is being reduced
+    float4 sa[8], sb[8];
+    PairItem pi = items[it_begin < it_end ? it_begin : 0];
+    if (it_begin < it_end) {
+        const float4* xi = spec + (wbase + pi.i) * (8 * kThreads);
+        const float4* xj = spec + (wbase + pi.j) * (8 * kThreads);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            sa[j] = xi[j * kThreads + t];
+            sb[j] = xj[j * kThreads + t];
+        }
+    }
+    for (int it = it_begin; it < it_end; ++it) {
+        const int out_idx = pi.out;
+        float2 v[16];
+        // R = X_j * conj(X_i), written (im, re)-swapped: the forward blocks below then compute the
+        // inverse transform (swap o F o swap = conj F).
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float4 a = sa[j];
+            const float4 b = sb[j];
+            v[2 * j] = make_float2(b.y * a.x - b.x * a.y, b.x * a.x + b.y * a.y);
+            v[2 * j + 1] = make_float2(b.w * a.z - b.z * a.w, b.z * a.z + b.w * a.w);
+        }
+        dft16(v);                     // k2 -> n0   (role C)
+        mul_tw2(v, tw2_lds, u & 15);  // W_256^(k1*n0)
+        xchg_bc_write_c(xl, v, t);
+        wave_lds_fence();
+        xchg_bc_read_b(xl, v, t);
+        dft16(v);                     // k1 -> n1   (role B)
+        // TW1 is re-read every pair (64 KiB per workgroup from L2) instead of living in 32 VGPRs;
+        // the pointer is laundered so that the loads stay here, in flight across the exchange.
+        float2 tw1[16];
+        {
+            const float4* twp = tw1_g;
+            asm volatile("" : "+s"(twp));
+            load_tw1(tw1, twp, t);
+        }
+        __syncthreads();              // all waves finished with their B<->C slices
+        xchg_b_write(xl, v, t);
+        __syncthreads();
+        xchg_a_read(xl, v, t);
+        mul_tw1(v, tw1);              // W_M^(u*k0) [* W_L^u on odd lanes]
+        dft16(v);                     // k0 -> n2   (role A): lane holds e[n] (p=0) or o[n]*W_L^u (p=1)
+        if (p) {
+#pragma unroll
+            for (int q = 1; q < 16; ++q) v[q] = cmul(v[q], w32(q));
+        }
+        // last radix-2 stage across the lane pair: even lane r[n] = e + o', odd lane r[n+M] = e - o'
+        float mag[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float rx = sgn * v[q].x + dpp_xor1(v[q].x);
+            const float ry = sgn * v[q].y + dpp_xor1(v[q].y);
+            mag[q] = rx * rx + ry * ry;
+        }
+        // 'full' order index of slot q: even lanes lag tau = n >= 0 -> k = n + M - 1;
+        // odd lanes tau = n - M -> k = n - 1 (n = 0, i.e. tau = -M, is not part of 'full').
+        if (it + 1 < it_end) {
+            pi = items[it + 1];
+            const float4* xi = spec + (wbase + pi.i) * (8 * kThreads);
+            const float4* xj = spec + (wbase + pi.j) * (8 * kThreads);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                sa[j] = xi[j * kThreads + t];
+                sb[j] = xj[j * kThreads + t];
+            }
+        }
+        if (p && u == 0) mag[0] = -1.0f;
+        float tmax = mag[0];
+#pragma unroll
+        for (int q = 1; q < 16; ++q) tmax = fmaxf(tmax, mag[q]);
+        float wmax = tmax;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, off, 64));
+        if (lane == 0) red_max[wave] = wmax;
+        if (t == 0) *red_k = 0x7fffffff;
+        __syncthreads();
+        float gmax = red_max[0];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) gmax = fmaxf(gmax, red_max[w]);
+        const int kbase = p ? (u - 1) : (u + kM - 1);
+        if (tmax == gmax) {
+            int kmin = 0x7fffffff;
+#pragma unroll
+            for (int q = 15; q >= 0; --q)
+                if (mag[q] == gmax) kmin = kbase + q * 256;
+            atomicMin(red_k, kmin);
+        }
+        __syncthreads();
+        const int kstar = *red_k;
+        // owners of taps k*-1, k*, k*+1 publish |r| (scipy scaling)
+#pragma unroll
+        for (int d = -1; d <= 1; ++d) {
+            const int kk = kstar + d;
+            if (kk >= 0 && kk <= 2 * kM - 2) {
+                const int par = (kk >= kM - 1) ? 0 : 1;
+                const int n = par ? (kk + 1) : (kk - (kM - 1));
+                if (p == par && u == (n & 255)) {
+                    const int qo = n >> 8;
+                    float val = 0.0f;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q)
+                        if (q == qo) val = mag[q];
+                    red_tap[d + 1] = sqrtf(val) * out_scale;
+                }
+            }
+        }
+        __syncthreads();
+        if (t == 0) {
+            const double b = (double)red_tap[1];
+            double frac = 0.0;
+            if (kstar > 0 && kstar < 2 * kM - 2) {
+                const double a = (double)red_tap[0], c = (double)red_tap[2];
+                const double den = a - 2.0 * b + c;
+                if (den != 0.0) frac = 0.5 * (a - c) / den;
+            }
+            const long o = (first_window + wl) * (long)n_pairs + out_idx;
+            lag_int[o] = kstar - (kM - 1);
+            lag_frac[o] = (float)frac;
+            peak[o] = (float)b;
+        }
+    }
+}
+
+// ================================================================================================
+// host side
+// ================================================================================================
+static thread_local std::string g_create_error;
+
+}  // namespace rmx
+
+struct rmx_ctx {
+    int device = 0;
+    int n_buoys = 0, n_samples = 0, max_windows = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int chunk_windows = 0;
+    int pairs_per_block = 7;
+    bool timing = false;
+    // device buffers
+    float4* d_spec = nullptr;
+    float4* d_tw1 = nullptr;
+    float2* d_tw2 = nullptr;
+    rmx::PairItem* d_items = nullptr;
+    int* d_part_begin = nullptr;
+    void* d_in = nullptr;      size_t d_in_bytes = 0;
+    int* d_lag = nullptr;      float* d_frac = nullptr;  float* d_peak = nullptr;  size_t d_out_elems = 0;
+    size_t spec_bytes = 0, scratch_bytes = 0;
+    // cached pair plan
+    std::vector<int32_t> plan_pairs;
+    int plan_n_pairs = -1, plan_n_parts = 0, plan_ppb = 0;
+    // timing
+    std::vector<hipEvent_t> ev;
+    std::vector<int> ev_kind;  // 0 fwd, 1 pair (per launch: ev[2k], ev[2k+1])
+    size_t ev_used = 0;
+    float t_fwd = 0, t_pair = 0;
+    int n_fwd = 0, n_pair = 0;
+    std::string err;
+};
+
+namespace rmx {
+
+static int fail(rmx_ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define RMX_HIP(c, call)                                                                          \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail((c), RMX_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),    \
+                        __FILE__, __LINE__);                                                      \
+    } while (0)
+
+static bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
+
+static void build_tables(std::vector<float4>& tw1, std::vector<float2>& tw2) {
+    const double two_pi = 6.283185307179586476925286766559;
+    tw1.resize(8 * kThreads);
+    std::vector<float2> t1(16 * kThreads);
+    for (int t = 0; t < kThreads; ++t) {
+        const int p = t & 1, u = t >> 1;
+        for (int k0 = 0; k0 < 16; ++k0) {
+            // W_M^(u*k0) * (p ? W_L^u : 1), W_n = exp(-2*pi*i/n)
+            double ang = -two_pi * (double)((u * k0) % kM) / (double)kM;
+            if (p) ang += -two_pi * (double)u / (double)kL;
+            t1[k0 * kThreads + t] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+        }
+    }
+    for (int j = 0; j < 8; ++j)
+        for (int t = 0; t < kThreads; ++t) {
+            const float2 a = t1[(2 * j) * kThreads + t], b = t1[(2 * j + 1) * kThreads + t];
+            tw1[j * kThreads + t] = make_float4(a.x, a.y, b.x, b.y);
+        }
+    tw2.resize(256);
+    for (int a = 0; a < 16; ++a)
+        for (int b = 0; b < 16; ++b) {
+            const double ang = -two_pi * (double)((a * b) % 256) / 256.0;
+            tw2[a * 16 + b] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+        }
+}
+
+static int ensure_events(rmx_ctx* c, size_t n) {
+    while (c->ev.size() < n) {
+        hipEvent_t e;
+        RMX_HIP(c, hipEventCreate(&e));
+        c->ev.push_back(e);
+    }
+    return RMX_OK;
+}
+
+// pair plan: items sorted as given, cut into parts of <= pairs_per_block consecutive items
+static int build_plan(rmx_ctx* c, const int32_t* pairs, int n_pairs) {
+    std::vector<int32_t> pl;
+    if (pairs) {
+        pl.assign(pairs, pairs + 2 * (size_t)n_pairs);
+    } else {
+        for (int i = 0; i < c->n_buoys; ++i)
+            for (int j = i + 1; j < c->n_buoys; ++j) { pl.push_back(i); pl.push_back(j); }
+    }
+    if (c->plan_n_pairs == n_pairs && c->plan_ppb == c->pairs_per_block && pl == c->plan_pairs) return RMX_OK;
+    for (int q = 0; q < n_pairs; ++q) {
+        const int i = pl[2 * q], j = pl[2 * q + 1];
+        if (i < 0 || j < 0 || i >= c->n_buoys || j >= c->n_buoys)
+            return fail(c, RMX_E_INVAL, "pair %d = (%d,%d) out of range for %d buoys", q, i, j, c->n_buoys);
+    }
+    std::vector<PairItem> items(n_pairs);
+    for (int q = 0; q < n_pairs; ++q) items[q] = PairItem{pl[2 * q], pl[2 * q + 1], q, 0};
+    const int ppb = c->pairs_per_block > 0 ? c->pairs_per_block : 7;
+    const int n_parts = (n_pairs + ppb - 1) / ppb;
+    std::vector<int> pb(n_parts + 1);
+    for (int k = 0; k <= n_parts; ++k) pb[k] = (int)((long)k * n_pairs / n_parts);
+    if (c->d_items) { (void)hipFree(c->d_items); c->d_items = nullptr; }
+    if (c->d_part_begin) { (void)hipFree(c->d_part_begin); c->d_part_begin = nullptr; }
+    RMX_HIP(c, hipMalloc((void**)&c->d_items, sizeof(PairItem) * (size_t)n_pairs));
+    RMX_HIP(c, hipMalloc((void**)&c->d_part_begin, sizeof(int) * (size_t)(n_parts + 1)));
+    RMX_HIP(c, hipMemcpy(c->d_items, items.data(), sizeof(PairItem) * (size_t)n_pairs, hipMemcpyHostToDevice));
+    RMX_HIP(c, hipMemcpy(c->d_part_begin, pb.data(), sizeof(int) * (size_t)(n_parts + 1), hipMemcpyHostToDevice));
+    c->plan_pairs.swap(pl);
+    c->plan_n_pairs = n_pairs;
+    c->plan_n_parts = n_parts;
+    c->plan_ppb = c->pairs_per_block;
+    return RMX_OK;
+}
+
+}  // namespace rmx
+
+using namespace rmx;
+
+extern "C" {
+
+int rmx_version(void) { return RMX_VERSION; }
+
+int rmx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+const char* rmx_last_error(const rmx_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int rmx_create(rmx_ctx** out, int device_id, int n_buoys, int n_samples, int max_windows, unsigned flags) {
+    if (!out) return fail(nullptr, RMX_E_INVAL, "out is NULL");
+    *out = nullptr;
+    (void)flags;
+    if (n_buoys < 2 || n_buoys > 4096) return fail(nullptr, RMX_E_INVAL, "n_buoys %d not in 2..4096", n_buoys);
+    if (!is_pow2(n_samples) || n_samples < 16 || n_samples > (1 << 22))
+        return fail(nullptr, RMX_E_INVAL, "n_samples %d must be a power of two in 16..4194304", n_samples);
+    if (max_windows < 1) return fail(nullptr, RMX_E_INVAL, "max_windows %d < 1", max_windows);
+    if (n_samples != kM)
+        return fail(nullptr, RMX_E_UNSUPPORTED, "n_samples %d: this build has the LDS-resident path for %d only",
+                    n_samples, kM);
+    int ndev = rmx_device_count();
+    if (ndev <= 0) return fail(nullptr, RMX_E_NODEV, "no HIP device visible");
+    if (device_id < 0 || device_id >= ndev) return fail(nullptr, RMX_E_INVAL, "device_id %d not in 0..%d", device_id, ndev - 1);
+    rmx_ctx* c = new (std::nothrow) rmx_ctx();
+    if (!c) return fail(nullptr, RMX_E_NOMEM, "host allocation failed");
+    c->device = device_id;
+    c->n_buoys = n_buoys;
+    c->n_samples = n_samples;
+    c->max_windows = max_windows;
+    int rc = RMX_OK;
+    auto bail = [&](int code) {
+        g_create_error = c->err;
+        rmx_destroy(c);
+        return code;
+    };
+    auto init = [&]() -> int {
+        RMX_HIP(c, hipSetDevice(device_id));
+        RMX_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+        const char* env = getenv("RMX_CHUNK_WINDOWS");
+        int chunk = env ? atoi(env) : 512;
+        if (chunk < 8) chunk = 8;
+        chunk = (chunk + 7) & ~7;
+        if (chunk > max_windows) chunk = max_windows;
+        c->chunk_windows = chunk;
+        c->spec_bytes = (size_t)chunk * n_buoys * (8 * kThreads) * sizeof(float4);
+        RMX_HIP(c, hipMalloc((void**)&c->d_spec, c->spec_bytes));
+        std::vector<float4> tw1;
+        std::vector<float2> tw2;
+        build_tables(tw1, tw2);
+        RMX_HIP(c, hipMalloc((void**)&c->d_tw1, tw1.size() * sizeof(float4)));
+        RMX_HIP(c, hipMalloc((void**)&c->d_tw2, tw2.size() * sizeof(float2)));
+        RMX_HIP(c, hipMemcpy(c->d_tw1, tw1.data(), tw1.size() * sizeof(float4), hipMemcpyHostToDevice));
+        RMX_HIP(c, hipMemcpy(c->d_tw2, tw2.data(), tw2.size() * sizeof(float2), hipMemcpyHostToDevice));
+        c->scratch_bytes = c->spec_bytes + tw1.size() * sizeof(float4) + tw2.size() * sizeof(float2);
+        RMX_HIP(c, hipFuncSetAttribute((const void*)k_fwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+        RMX_HIP(c, hipFuncSetAttribute((const void*)k_fwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+        RMX_HIP(c, hipFuncSetAttribute((const void*)k_pair, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+        return RMX_OK;
+    };
+    rc = init();
+    if (rc != RMX_OK) return bail(rc);
+    *out = c;
+    return RMX_OK;
+}
+
+void rmx_destroy(rmx_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+    if (c->d_spec) (void)hipFree(c->d_spec);
+    if (c->d_tw1) (void)hipFree(c->d_tw1);
+    if (c->d_tw2) (void)hipFree(c->d_tw2);
+    if (c->d_items) (void)hipFree(c->d_items);
+    if (c->d_part_begin) (void)hipFree(c->d_part_begin);
+    if (c->d_in) (void)hipFree(c->d_in);
+    if (c->d_lag) (void)hipFree(c->d_lag);
+    if (c->d_frac) (void)hipFree(c->d_frac);
+    if (c->d_peak) (void)hipFree(c->d_peak);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int rmx_set_stream(rmx_ctx* c, void* hip_stream) {
+    if (!c) return RMX_E_INVAL;
+    RMX_HIP(c, hipSetDevice(c->device));
+    if (c->stream) RMX_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    c->stream = (hipStream_t)hip_stream;
+    c->own_stream = false;
+    return RMX_OK;
+}
+
+int rmx_set_option(rmx_ctx* c, const char* key, long value) {
+    if (!c || !key) return RMX_E_INVAL;
+    if (!strcmp(key, "chunk_windows")) {
+        long chunk = value < 8 ? 8 : value;
+        chunk = (chunk + 7) & ~7L;
+        if (chunk > c->max_windows) chunk = c->max_windows;
+        if (chunk != c->chunk_windows) {
+            RMX_HIP(c, hipSetDevice(c->device));
+            RMX_HIP(c, hipStreamSynchronize(c->stream));
+            const size_t nb = (size_t)chunk * c->n_buoys * (8 * kThreads) * sizeof(float4);
+            float4* nspec = nullptr;
+            RMX_HIP(c, hipMalloc((void**)&nspec, nb));
+            (void)hipFree(c->d_spec);
+            c->d_spec = nspec;
+            c->scratch_bytes += nb - c->spec_bytes;
+            c->spec_bytes = nb;
+            c->chunk_windows = (int)chunk;
+        }
+        return RMX_OK;
+    }
+    if (!strcmp(key, "pairs_per_block")) {
+        if (value < 1 || value > 1 << 20) return fail(c, RMX_E_INVAL, "pairs_per_block %ld out of range", value);
+        c->pairs_per_block = (int)value;
+        return RMX_OK;
+    }
+    if (!strcmp(key, "timing")) {
+        c->timing = value != 0;
+        return RMX_OK;
+    }
+    return fail(c, RMX_E_INVAL, "unknown option '%s'", key);
+}
+
+int rmx_xcorr_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pairs, int n_pairs,
+                    int32_t* lag_int, float* lag_frac, float* peak, unsigned flags) {
+    if (!c) return RMX_E_INVAL;
+    if (!iq || !lag_int || !lag_frac || !peak) return fail(c, RMX_E_INVAL, "NULL buffer");
+    if (n_windows < 0 || n_windows > c->max_windows)
+        return fail(c, RMX_E_INVAL, "n_windows %d not in 0..max_windows=%d", n_windows, c->max_windows);
+    const int all_pairs = c->n_buoys * (c->n_buoys - 1) / 2;
+    if (!pairs) {
+        if (n_pairs != 0 && n_pairs != all_pairs)
+            return fail(c, RMX_E_INVAL, "pairs == NULL needs n_pairs == 0 or %d, got %d", all_pairs, n_pairs);
+        n_pairs = all_pairs;
+    }
+    if (n_pairs < 0) return fail(c, RMX_E_INVAL, "n_pairs %d < 0", n_pairs);
+    if (n_windows == 0 || n_pairs == 0) return RMX_OK;
+    RMX_HIP(c, hipSetDevice(c->device));
+    int rc = build_plan(c, pairs, n_pairs);
+    if (rc != RMX_OK) return rc;
+
+    const bool in_dev = flags & RMX_IN_DEVICE, out_dev = flags & RMX_OUT_DEVICE, u8 = flags & RMX_IN_U8;
+    const size_t samp_bytes = u8 ? 2 : 8;
+    const size_t in_bytes = (size_t)n_windows * c->n_buoys * c->n_samples * samp_bytes;
+    const void* d_iq = iq;
+    if (!in_dev) {
+        if (c->d_in_bytes < in_bytes) {
+            if (c->d_in) (void)hipFree(c->d_in);
+            c->d_in = nullptr;
+            c->d_in_bytes = 0;
+            RMX_HIP(c, hipMalloc(&c->d_in, in_bytes));
+            c->d_in_bytes = in_bytes;
+        }
+        RMX_HIP(c, hipMemcpyAsync(c->d_in, iq, in_bytes, hipMemcpyHostToDevice, c->stream));
+        d_iq = c->d_in;
+    }
+    int* d_lag = lag_int;
+    float* d_frac = lag_frac;
+    float* d_peak = peak;
+    const size_t out_elems = (size_t)n_windows * n_pairs;
+    if (!out_dev) {
+        if (c->d_out_elems < out_elems) {
+            if (c->d_lag) (void)hipFree(c->d_lag);
+            if (c->d_frac) (void)hipFree(c->d_frac);
+            if (c->d_peak) (void)hipFree(c->d_peak);
+            c->d_lag = nullptr; c->d_frac = nullptr; c->d_peak = nullptr; c->d_out_elems = 0;
+            RMX_HIP(c, hipMalloc((void**)&c->d_lag, out_elems * sizeof(int)));
+            RMX_HIP(c, hipMalloc((void**)&c->d_frac, out_elems * sizeof(float)));
+            RMX_HIP(c, hipMalloc((void**)&c->d_peak, out_elems * sizeof(float)));
+            c->d_out_elems = out_elems;
+        }
+        d_lag = c->d_lag; d_frac = c->d_frac; d_peak = c->d_peak;
+    }
+
+    // power-of-two scaling: spectra carry 2^-hs, the product 2^-2hs, the taps the remaining factor
+    int logl = 0;
+    while ((1 << logl) < kL) ++logl;
+    const int hs = logl / 2;
+    const float fwd_scale = std::ldexp(1.0f, -hs);
+    const float out_scale = std::ldexp(1.0f, -(logl - 2 * hs));
+
+    const int n_parts = c->plan_n_parts;
+    const int n_chunks = (n_windows + c->chunk_windows - 1) / c->chunk_windows;
+    c->ev_used = 0;
+    c->ev_kind.clear();
+    if (c->timing) {
+        rc = ensure_events(c, (size_t)n_chunks * 4);
+        if (rc != RMX_OK) return rc;
+    }
+    for (int w0 = 0; w0 < n_windows; w0 += c->chunk_windows) {
+        const int wc = (n_windows - w0 < c->chunk_windows) ? n_windows - w0 : c->chunk_windows;
+        const long first_item = (long)w0 * c->n_buoys;
+        const int n_items = wc * c->n_buoys;
+        if (c->timing) RMX_HIP(c, hipEventRecord(c->ev[c->ev_used], c->stream));
+        if (u8)
+            hipLaunchKernelGGL(k_fwd<true>, dim3(n_items), dim3(kThreads), kLdsBytes, c->stream, d_iq, c->d_spec,
+                               c->d_tw1, c->d_tw2, first_item, fwd_scale);
+        else
+            hipLaunchKernelGGL(k_fwd<false>, dim3(n_items), dim3(kThreads), kLdsBytes, c->stream, d_iq, c->d_spec,
+                               c->d_tw1, c->d_tw2, first_item, fwd_scale);
+        RMX_HIP(c, hipGetLastError());
+        if (c->timing) {
+            RMX_HIP(c, hipEventRecord(c->ev[c->ev_used + 1], c->stream));
+            c->ev_used += 2;
+            c->ev_kind.push_back(0);
+            RMX_HIP(c, hipEventRecord(c->ev[c->ev_used], c->stream));
+        }
+        const int xcd_map = (wc % 8 == 0) ? 1 : 0;
+        hipLaunchKernelGGL(k_pair, dim3(wc * n_parts), dim3(kThreads), kLdsBytes, c->stream, c->d_spec, c->d_tw1,
+                           c->d_tw2, c->d_items, c->d_part_begin, n_parts, c->n_buoys, n_pairs, wc, xcd_map,
+                           (long)w0, out_scale, d_lag, d_frac, d_peak);
+        RMX_HIP(c, hipGetLastError());
+        if (c->timing) {
+            RMX_HIP(c, hipEventRecord(c->ev[c->ev_used + 1], c->stream));
+            c->ev_used += 2;
+            c->ev_kind.push_back(1);
+        }
+    }
+    if (!out_dev) {
+        RMX_HIP(c, hipMemcpyAsync(lag_int, d_lag, out_elems * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        RMX_HIP(c, hipMemcpyAsync(lag_frac, d_frac, out_elems * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        RMX_HIP(c, hipMemcpyAsync(peak, d_peak, out_elems * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        RMX_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    return RMX_OK;
+}
+
+int rmx_synchronize(rmx_ctx* c) {
+    if (!c) return RMX_E_INVAL;
+    RMX_HIP(c, hipSetDevice(c->device));
+    RMX_HIP(c, hipStreamSynchronize(c->stream));
+    return RMX_OK;
+}
+
+int rmx_last_timing(rmx_ctx* c, float* fwd_ms, int* fwd_launches, float* pair_ms, int* pair_launches) {
+    if (!c) return RMX_E_INVAL;
+    RMX_HIP(c, hipSetDevice(c->device));
+    RMX_HIP(c, hipStreamSynchronize(c->stream));
+    float tf = 0, tp = 0;
+    int nf = 0, np = 0;
+    for (size_t k = 0; k < c->ev_kind.size(); ++k) {
+        float ms = 0;
+        RMX_HIP(c, hipEventElapsedTime(&ms, c->ev[2 * k], c->ev[2 * k + 1]));
+        if (c->ev_kind[k] == 0) { tf += ms; ++nf; } else { tp += ms; ++np; }
+    }
+    if (fwd_ms) *fwd_ms = tf;
+    if (fwd_launches) *fwd_launches = nf;
+    if (pair_ms) *pair_ms = tp;
+    if (pair_launches) *pair_launches = np;
+    return RMX_OK;
+}
+
+size_t rmx_scratch_bytes(const rmx_ctx* c) { return c ? c->scratch_bytes : 0; }
+
+}  // extern "C"

@@ -1,0 +1,351 @@
+"""Host-side mirror of the reference's ``tdoa_processor.py`` interface, with the pair loop's time
+difference measured from IQ on the GPU.
+
+Same public names, argument meaning and error behaviour as the reference module so that
+``central_processor.py`` / the reference's tests can switch imports:
+
+  reference item (tdoa_processor.py)                      here
+  -----------------------------------------------------  ------------------------------------------
+  BuoyPosition / SignalDetection / TDoAMeasurement /      same field names and order (:24-69);
+  TriangulationResult dataclasses                          SignalDetection gains two OPTIONAL trailing
+                                                           fields (iq_samples, sample_rate_hz)
+  GeodeticCalculator (:71-136)                             same statics (spherical ECEF, R=6378137)
+  TDoACalculator.calculate_tdoa_measurements (:146-198)    same pair order / skips / confidence;
+                                                           ``time_diff_ns`` (:166) becomes
+                                                           window-start difference + xcorr lag when
+                                                           every detection carries IQ
+  HyperbolicPositioning.triangulate_position (:218-328)    same objective, BFGS, result fields
+  TDoAProcessor (:330-465)                                 same ctor / register_buoy /
+                                                           process_signal_detections / status
+
+Without IQ on the detections every number equals the reference's (pinned by
+tests/golden/tdoa_conventions.json).  With IQ the lag comes from ``xcorr.XcorrEngine`` (HIP, gfx950);
+there is no CPU fallback: if IQ is supplied and the HIP library or a GPU is missing, the engine
+constructor raises (ImportError / RmxError) instead of silently degrading to timestamps.
+"""
+from __future__ import annotations
+
+import logging
+import math
+from dataclasses import dataclass
+from datetime import datetime, timezone
+from typing import Any, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+logger = logging.getLogger(__name__)
+
+_C = 299792458.0
+
+
+# --------------------------------------------------------------------------------------------------
+# data model (field names/order: tdoa_processor.py:24-69; tests construct these positionally)
+# --------------------------------------------------------------------------------------------------
+@dataclass
+class BuoyPosition:
+    buoy_id: str
+    lat: float
+    lng: float
+    altitude: float = 0.0
+    timing_accuracy_ns: int = 100000
+
+
+@dataclass
+class SignalDetection:
+    buoy_id: str
+    frequency_mhz: float
+    signal_strength_dbm: float
+    timestamp_utc: str
+    gps_timestamp_ns: int
+    lat: float
+    lng: float
+    confidence: float
+    signal_type: str = "unknown"
+    # extension (not in the reference): the capture window this detection was made on.
+    # gps_timestamp_ns is then the time tag of the window's first sample.
+    iq_samples: Optional[Any] = None          # np.ndarray complex64 [N] or raw uint8 [2N]
+    sample_rate_hz: Optional[float] = None
+
+
+@dataclass
+class TDoAMeasurement:
+    buoy1_id: str
+    buoy2_id: str
+    time_difference_ns: int        # buoy2 - buoy1; > 0 when buoy2 received later
+    distance_difference_m: float
+    confidence: float
+    frequency_mhz: float
+
+
+@dataclass
+class TriangulationResult:
+    estimated_lat: float
+    estimated_lng: float
+    estimated_altitude: float
+    accuracy_meters: float
+    confidence: float
+    frequency_mhz: float
+    signal_type: str
+    timestamp_utc: str
+    contributing_buoys: List[str]
+    tdoa_measurements: List[TDoAMeasurement]
+    method: str
+
+    @property
+    def accuracy_estimate_meters(self) -> float:
+        """Name central_processor.py:434 reads (absent in the reference: SURVEY.md section 0.2)."""
+        return self.accuracy_meters
+
+
+class GeodeticCalculator:
+    """Spherical-earth helpers with the reference's constants (tdoa_processor.py:71-136)."""
+
+    EARTH_RADIUS_M = 6378137.0
+
+    @staticmethod
+    def lat_lng_to_xyz(lat: float, lng: float, alt: float = 0.0) -> Tuple[float, float, float]:
+        phi, lam = math.radians(lat), math.radians(lng)
+        r = GeodeticCalculator.EARTH_RADIUS_M + alt
+        c = math.cos(phi)
+        return r * c * math.cos(lam), r * c * math.sin(lam), r * math.sin(phi)
+
+    @staticmethod
+    def xyz_to_lat_lng(x: float, y: float, z: float) -> Tuple[float, float, float]:
+        rho = math.sqrt(x * x + y * y)
+        return (math.degrees(math.atan2(z, rho)), math.degrees(math.atan2(y, x)),
+                math.sqrt(x * x + y * y + z * z) - GeodeticCalculator.EARTH_RADIUS_M)
+
+    @staticmethod
+    def distance_3d(lat1, lng1, alt1, lat2, lng2, alt2) -> float:
+        a = GeodeticCalculator.lat_lng_to_xyz(lat1, lng1, alt1)
+        b = GeodeticCalculator.lat_lng_to_xyz(lat2, lng2, alt2)
+        return math.sqrt(sum((q - p) ** 2 for p, q in zip(a, b)))
+
+    @staticmethod
+    def bearing_distance(lat1, lng1, lat2, lng2) -> Tuple[float, float]:
+        p1, p2 = math.radians(lat1), math.radians(lat2)
+        dl = math.radians(lng2 - lng1)
+        h = math.sin((p2 - p1) / 2) ** 2 + math.cos(p1) * math.cos(p2) * math.sin(dl / 2) ** 2
+        dist = GeodeticCalculator.EARTH_RADIUS_M * 2 * math.atan2(math.sqrt(h), math.sqrt(1 - h))
+        brg = math.atan2(math.sin(dl) * math.cos(p2),
+                         math.cos(p1) * math.sin(p2) - math.sin(p1) * math.cos(p2) * math.cos(dl))
+        return (math.degrees(brg) + 360) % 360, dist
+
+
+# --------------------------------------------------------------------------------------------------
+# the seam: pairwise TDoA
+# --------------------------------------------------------------------------------------------------
+class TDoACalculator:
+    SPEED_OF_LIGHT = _C  # tdoa_processor.py:141
+
+    def __init__(self, device: int = 0):
+        self.logger = logging.getLogger(__name__ + ".TDoACalculator")
+        self.device = device
+        self._engines: Dict[Tuple[int, int], Any] = {}
+
+    # -- GPU engine cache ------------------------------------------------------------------------
+    def _engine(self, n_buoys: int, n_samples: int, n_windows: int = 1):
+        from . import xcorr  # raises ImportError loudly if the HIP library is not built
+        key = (n_buoys, n_samples)
+        eng = self._engines.get(key)
+        if eng is None or eng.max_windows < n_windows:
+            if eng is not None:
+                eng.close()
+            eng = xcorr.XcorrEngine(n_buoys, n_samples, max(n_windows, 1), device=self.device)
+            self._engines[key] = eng
+        return eng
+
+    def measure_lags(self, iq, pairs=None):
+        """Batched hot path: iq complex64 [W][B][N] (or uint8 [W][B][2N]) ->
+        (lag_int [W][P], lag_frac [W][P], peak [W][P]); lag = delay(j) - delay(i) in samples."""
+        iq = np.asarray(iq)
+        n = iq.shape[2] // 2 if iq.dtype == np.uint8 else iq.shape[2]
+        return self._engine(iq.shape[1], n, iq.shape[0]).correlate(iq, pairs)
+
+    @staticmethod
+    def _iq_of(det: SignalDetection):
+        s = det.iq_samples
+        if s is None or det.sample_rate_hz is None:
+            return None
+        a = np.asarray(s)
+        if a.dtype == np.uint8:
+            return a
+        return np.ascontiguousarray(a, dtype=np.complex64)
+
+    def _timing_confidence(self, b1: BuoyPosition, b2: BuoyPosition) -> float:
+        # exp(-rss(timing accuracies) / 100 us), capped at 1 (tdoa_processor.py:200-210)
+        return min(math.exp(-math.hypot(b1.timing_accuracy_ns, b2.timing_accuracy_ns) / 100000), 1.0)
+
+    _calculate_timing_confidence = _timing_confidence  # reference's private name
+
+    def calculate_tdoa_measurements(self, detections: List[SignalDetection],
+                                    buoy_positions: Dict[str, BuoyPosition]) -> List[TDoAMeasurement]:
+        out: List[TDoAMeasurement] = []
+        nd = len(detections)
+        if nd < 2:
+            self.logger.warning("Need at least 2 detections for TDoA calculation")
+            return out
+        iqs = [self._iq_of(d) for d in detections]
+        lag = None
+        if all(a is not None for a in iqs):
+            shapes = {(a.dtype.str, a.shape) for a in iqs}
+            rates = {float(d.sample_rate_hz) for d in detections}
+            if len(shapes) == 1 and len(rates) == 1:
+                li, lf, _ = self.measure_lags(np.stack(iqs)[None])
+                lag = li[0].astype(np.float64) + lf[0].astype(np.float64)
+                fs = rates.pop()
+            else:
+                self.logger.warning("IQ windows differ in length/dtype/sample rate; using time tags only")
+        q = -1
+        for i in range(nd):
+            for j in range(i + 1, nd):
+                q += 1
+                d1, d2 = detections[i], detections[j]
+                if abs(d1.frequency_mhz - d2.frequency_mhz) > 0.01:
+                    continue
+                dt_ns = d2.gps_timestamp_ns - d1.gps_timestamp_ns
+                if lag is not None:
+                    dt_ns += int(round(lag[q] / fs * 1e9))
+                dist_m = dt_ns / 1e9 * self.SPEED_OF_LIGHT
+                p1, p2 = buoy_positions.get(d1.buoy_id), buoy_positions.get(d2.buoy_id)
+                if not p1 or not p2:
+                    continue
+                conf = min(d1.confidence, d2.confidence) * self._timing_confidence(p1, p2)
+                out.append(TDoAMeasurement(d1.buoy_id, d2.buoy_id, dt_ns, dist_m, conf, d1.frequency_mhz))
+                self.logger.debug("TDoA %s-%s dT=%.1f us dD=%.1f m", d1.buoy_id, d2.buoy_id,
+                                  dt_ns / 1000, dist_m)
+        return out
+
+
+# --------------------------------------------------------------------------------------------------
+# consumer: hyperbolic fix (unchanged semantics; tdoa_processor.py:218-328)
+# --------------------------------------------------------------------------------------------------
+class HyperbolicPositioning:
+    def __init__(self):
+        self.logger = logging.getLogger(__name__ + ".HyperbolicPositioning")
+
+    def triangulate_position(self, measurements: List[TDoAMeasurement],
+                             buoy_positions: Dict[str, BuoyPosition]) -> Optional[TriangulationResult]:
+        if len(measurements) < 2:
+            self.logger.warning("Need at least 2 TDoA measurements for triangulation")
+            return None
+        ids = set()
+        for m in measurements:
+            ids.update((m.buoy1_id, m.buoy2_id))
+        if len(ids) < 3:
+            self.logger.warning("Need at least 3 buoys for 2D triangulation")
+            return None
+        xyz = {}
+        for b in ids:
+            if b not in buoy_positions:
+                self.logger.error(f"Missing position for buoy {b}")
+                return None
+            pos = buoy_positions[b]
+            xyz[b] = GeodeticCalculator.lat_lng_to_xyz(pos.lat, pos.lng, pos.altitude)
+        p1 = np.array([xyz[m.buoy1_id] for m in measurements])
+        p2 = np.array([xyz[m.buoy2_id] for m in measurements])
+        meas = np.array([m.distance_difference_m for m in measurements])
+        wgt = 1.0 / (np.array([m.confidence for m in measurements]) + 0.1)
+
+        def cost(tx):
+            d = np.linalg.norm(tx - p2, axis=1) - np.linalg.norm(tx - p1, axis=1)
+            return float(np.sum(wgt * (d - meas) ** 2))
+
+        x0 = np.mean(np.array(list(xyz.values())), axis=0)
+        try:
+            import scipy.optimize
+            res = scipy.optimize.minimize(cost, x0, method="BFGS", options={"maxiter": 1000})
+            if not res.success:
+                self.logger.warning(f"Optimization failed: {res.message}")
+                return None
+            lat, lng, alt = GeodeticCalculator.xyz_to_lat_lng(*res.x)
+            acc = math.sqrt(res.fun / len(measurements))
+            conf = sum(m.confidence for m in measurements) / len(measurements)
+            self.logger.info(f"Triangulation successful: ({lat:.6f}, {lng:.6f}) ±{acc:.1f}m, confidence: {conf:.2f}")
+            return TriangulationResult(lat, lng, alt, acc, conf, measurements[0].frequency_mhz, "unknown",
+                                       datetime.now(timezone.utc).isoformat(), list(ids), measurements,
+                                       "hyperbolic")
+        except Exception as e:  # reference convention: log, never raise (:326-328)
+            self.logger.error(f"Triangulation failed: {e}")
+            return None
+
+
+# --------------------------------------------------------------------------------------------------
+# orchestrator (tdoa_processor.py:330-465)
+# --------------------------------------------------------------------------------------------------
+class TDoAProcessor:
+    def __init__(self):
+        self.logger = logging.getLogger(__name__ + ".TDoAProcessor")
+        self.tdoa_calculator = TDoACalculator()
+        self.hyperbolic_positioner = HyperbolicPositioning()
+        self.buoy_positions: Dict[str, BuoyPosition] = {}
+        self.correlation_window_s = 10.0
+        self.min_buoys_for_triangulation = 3
+
+    def register_buoy(self, buoy_position: BuoyPosition):
+        self.buoy_positions[buoy_position.buoy_id] = buoy_position
+        self.logger.info(f"Registered buoy {buoy_position.buoy_id} at "
+                         f"({buoy_position.lat:.6f}, {buoy_position.lng:.6f})")
+
+    def _group_by_frequency(self, detections: Sequence[SignalDetection],
+                            frequency_tolerance_mhz: float = 0.01) -> Dict[float, List[SignalDetection]]:
+        """First-fit grouping on the group's first frequency (tdoa_processor.py:405-425)."""
+        groups: Dict[float, List[SignalDetection]] = {}
+        for d in detections:
+            key = next((f for f in groups if abs(d.frequency_mhz - f) <= frequency_tolerance_mhz), None)
+            if key is None:
+                groups[d.frequency_mhz] = [d]
+            else:
+                groups[key].append(d)
+        return groups
+
+    def _filter_by_time_window(self, detections: Sequence[SignalDetection]) -> List[SignalDetection]:
+        """Keep detections no older than correlation_window_s before the newest, sorted by time
+        (tdoa_processor.py:427-445)."""
+        if not detections:
+            return []
+        ordered = sorted(detections, key=lambda d: d.gps_timestamp_ns)
+        cutoff = ordered[-1].gps_timestamp_ns - int(self.correlation_window_s * 1e9)
+        return [d for d in ordered if d.gps_timestamp_ns >= cutoff]
+
+    def process_signal_detections(self, detections: List[SignalDetection]) -> List[TriangulationResult]:
+        if not detections:
+            return []
+        self.logger.info(f"Processing {len(detections)} signal detections")
+        results: List[TriangulationResult] = []
+        for freq, group in self._group_by_frequency(detections).items():
+            recent = self._filter_by_time_window(group)
+            if len(recent) < self.min_buoys_for_triangulation:
+                self.logger.debug(f"Insufficient detections for {freq} MHz ({len(recent)} < "
+                                  f"{self.min_buoys_for_triangulation})")
+                continue
+            meas = self.tdoa_calculator.calculate_tdoa_measurements(recent, self.buoy_positions)
+            if len(meas) < 2:
+                self.logger.debug(f"Insufficient TDoA measurements for {freq} MHz")
+                continue
+            fix = self.hyperbolic_positioner.triangulate_position(meas, self.buoy_positions)
+            if fix:
+                kinds = [d.signal_type for d in recent]
+                fix.signal_type = max(set(kinds), key=kinds.count)
+                results.append(fix)
+                if fix.signal_type == "emergency":
+                    self.logger.warning(f"EMERGENCY SIGNAL TRIANGULATED: {freq} MHz at "
+                                        f"({fix.estimated_lat:.6f}, {fix.estimated_lng:.6f}) "
+                                        f"±{fix.accuracy_meters:.1f}m")
+        return results
+
+    def triangulate_signal(self, detections: List[SignalDetection]) -> Optional[TriangulationResult]:
+        """What central_processor.py:418 calls (missing in the reference): first fix or None."""
+        res = self.process_signal_detections(detections)
+        return res[0] if res else None
+
+    def get_buoy_network_status(self) -> Dict:
+        return {
+            "registered_buoys": len(self.buoy_positions),
+            "buoy_list": [{"buoy_id": p.buoy_id, "lat": p.lat, "lng": p.lng,
+                           "timing_accuracy_ns": p.timing_accuracy_ns}
+                          for p in self.buoy_positions.values()],
+            "min_buoys_required": self.min_buoys_for_triangulation,
+            "correlation_window_s": self.correlation_window_s,
+            "triangulation_ready": len(self.buoy_positions) >= self.min_buoys_for_triangulation,
+        }

@@ -1,0 +1,196 @@
+"""ctypes binding of the C-ABI library (include/rmx.h) -- the only compute path of this package.
+
+There is no CPU fallback here: if ``librmx_hip.so`` is missing or no MI355X is visible the
+constructor raises.  (The CPU oracle lives in ``oracle/`` and is test infrastructure only.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_NAME = "librmx_hip.so"
+LIB_PATH = os.path.join(_HERE, "csrc", LIB_NAME)
+
+RMX_IN_DEVICE = 1
+RMX_OUT_DEVICE = 2
+RMX_IN_U8 = 4
+
+_lib = None
+
+
+class RmxError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"rmx error {code}: {msg}")
+        self.code = code
+
+
+def library_path() -> str:
+    return os.environ.get("RMX_LIBRARY", LIB_PATH)
+
+
+def load_library():
+    """dlopen the HIP library (once).  torch, when importable, is imported first so that this
+    library binds to the same libamdhip64 as torch (device pointers and streams are shared)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
+    lib = C.CDLL(path)
+    vp, ci, cu = C.c_void_p, C.c_int, C.c_uint
+    lib.rmx_version.restype = ci
+    lib.rmx_device_count.restype = ci
+    lib.rmx_create.argtypes = [C.POINTER(vp), ci, ci, ci, ci, cu]
+    lib.rmx_create.restype = ci
+    lib.rmx_destroy.argtypes = [vp]
+    lib.rmx_destroy.restype = None
+    lib.rmx_last_error.argtypes = [vp]
+    lib.rmx_last_error.restype = C.c_char_p
+    lib.rmx_set_stream.argtypes = [vp, vp]
+    lib.rmx_set_stream.restype = ci
+    lib.rmx_set_option.argtypes = [vp, C.c_char_p, C.c_long]
+    lib.rmx_set_option.restype = ci
+    lib.rmx_xcorr_batch.argtypes = [vp, vp, ci, vp, ci, vp, vp, vp, cu]
+    lib.rmx_xcorr_batch.restype = ci
+    lib.rmx_synchronize.argtypes = [vp]
+    lib.rmx_synchronize.restype = ci
+    lib.rmx_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(ci), C.POINTER(C.c_float),
+                                    C.POINTER(ci)]
+    lib.rmx_last_timing.restype = ci
+    lib.rmx_scratch_bytes.argtypes = [vp]
+    lib.rmx_scratch_bytes.restype = C.c_size_t
+    _lib = lib
+    return lib
+
+
+EXPORTS = ["rmx_version", "rmx_device_count", "rmx_create", "rmx_destroy", "rmx_last_error",
+           "rmx_set_stream", "rmx_set_option", "rmx_xcorr_batch", "rmx_synchronize",
+           "rmx_last_timing", "rmx_scratch_bytes"]
+
+
+def device_count() -> int:
+    return int(load_library().rmx_device_count())
+
+
+def pair_list(n_buoys: int) -> np.ndarray:
+    """(i, j), i < j, nested-loop order of tdoa_processor.py:156-157."""
+    return np.array([(i, j) for i in range(n_buoys) for j in range(i + 1, n_buoys)],
+                    dtype=np.int32).reshape(-1, 2)
+
+
+class XcorrEngine:
+    """One engine = one rmx_ctx = one GPU.  Batched pairwise cross-correlation lags."""
+
+    def __init__(self, n_buoys: int, n_samples: int, max_windows: int, device: int = 0):
+        self._lib = load_library()
+        self._ctx = C.c_void_p()
+        rc = self._lib.rmx_create(C.byref(self._ctx), device, n_buoys, n_samples, max_windows, 0)
+        if rc != 0:
+            msg = self._lib.rmx_last_error(None)
+            self._ctx = C.c_void_p()
+            raise RmxError(rc, msg.decode() if msg else "rmx_create failed")
+        self.n_buoys, self.n_samples, self.max_windows, self.device = n_buoys, n_samples, max_windows, device
+
+    # -- plumbing ------------------------------------------------------------------------------
+    def _check(self, rc: int):
+        if rc != 0:
+            msg = self._lib.rmx_last_error(self._ctx)
+            raise RmxError(rc, msg.decode() if msg else "?")
+
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx:
+            self._lib.rmx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_stream(self, hip_stream: int):
+        self._check(self._lib.rmx_set_stream(self._ctx, C.c_void_p(hip_stream)))
+
+    def set_option(self, key: str, value: int):
+        self._check(self._lib.rmx_set_option(self._ctx, key.encode(), int(value)))
+
+    def synchronize(self):
+        self._check(self._lib.rmx_synchronize(self._ctx))
+
+    def scratch_bytes(self) -> int:
+        return int(self._lib.rmx_scratch_bytes(self._ctx))
+
+    def last_timing(self) -> dict:
+        f, p = C.c_float(), C.c_float()
+        nf, npair = C.c_int(), C.c_int()
+        self._check(self._lib.rmx_last_timing(self._ctx, C.byref(f), C.byref(nf), C.byref(p), C.byref(npair)))
+        return dict(fwd_ms=f.value, fwd_launches=nf.value, pair_ms=p.value, pair_launches=npair.value)
+
+    # -- the hot path ----------------------------------------------------------------------------
+    def correlate(self, iq: np.ndarray, pairs: Optional[np.ndarray] = None
+                  ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """Host arrays in, host arrays out.  iq: complex64 [W][B][N] (or uint8 [W][B][2N] raw
+        rtl_sdr I,Q).  Returns (lag_int int32 [W][P], lag_frac float32 [W][P], peak float32 [W][P]);
+        lag = lag_int + lag_frac = delay(j) - delay(i) in samples."""
+        iq = np.asarray(iq)
+        flags = 0
+        if iq.dtype == np.uint8:
+            flags |= RMX_IN_U8
+            if iq.ndim != 3 or iq.shape[1] != self.n_buoys or iq.shape[2] != 2 * self.n_samples:
+                raise ValueError(f"uint8 iq must be [W][{self.n_buoys}][{2 * self.n_samples}], got {iq.shape}")
+        else:
+            iq = np.ascontiguousarray(iq, dtype=np.complex64)
+            if iq.ndim != 3 or iq.shape[1] != self.n_buoys or iq.shape[2] != self.n_samples:
+                raise ValueError(f"iq must be [W][{self.n_buoys}][{self.n_samples}], got {iq.shape}")
+        iq = np.ascontiguousarray(iq)
+        W = iq.shape[0]
+        if pairs is not None:
+            pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+            P = pairs.shape[0]
+            pp = pairs.ctypes.data_as(C.c_void_p)
+        else:
+            P = self.n_buoys * (self.n_buoys - 1) // 2
+            pp = None
+        lag_int = np.zeros((W, P), np.int32)
+        lag_frac = np.zeros((W, P), np.float32)
+        peak = np.zeros((W, P), np.float32)
+        if W == 0 or P == 0:
+            return lag_int, lag_frac, peak
+        self._check(self._lib.rmx_xcorr_batch(
+            self._ctx, iq.ctypes.data_as(C.c_void_p), W, pp, P,
+            lag_int.ctypes.data_as(C.c_void_p), lag_frac.ctypes.data_as(C.c_void_p),
+            peak.ctypes.data_as(C.c_void_p), flags))
+        return lag_int, lag_frac, peak
+
+    def correlate_device(self, iq_ptr: int, n_windows: int, lag_int_ptr: int, lag_frac_ptr: int,
+                         peak_ptr: int, pairs: Optional[np.ndarray] = None, u8: bool = False):
+        """Device pointers in and out (inputs already resident in HBM); asynchronous on the ctx
+        stream."""
+        if pairs is not None:
+            pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+            P = pairs.shape[0]
+            pp = pairs.ctypes.data_as(C.c_void_p)
+        else:
+            P = self.n_buoys * (self.n_buoys - 1) // 2
+            pp = None
+        flags = RMX_IN_DEVICE | RMX_OUT_DEVICE | (RMX_IN_U8 if u8 else 0)
+        self._check(self._lib.rmx_xcorr_batch(self._ctx, C.c_void_p(iq_ptr), n_windows, pp, P,
+                                              C.c_void_p(lag_int_ptr), C.c_void_p(lag_frac_ptr),
+                                              C.c_void_p(peak_ptr), flags))

@@ -1,0 +1,176 @@
+"""Parity of the HIP path (through the C ABI) against the oracle and the golden fixtures.
+Bars: integer lag bit-exact; |lag - lag_ref| <= 1e-5 * max(|lag_ref|, 1); peak rtol 1e-5.
+
+Where two candidate peaks are closer than 1e-5 relative in the *oracle's own* magnitudes the integer
+argmax is decided by float32 rounding order of the FFT used (pocketfft vs ours); such pair-windows
+are reported and accepted only if the GPU pick is one of those candidates (none occur in the
+committed fixtures: their smallest margin is 2.3e-3)."""
+import os
+
+import numpy as np
+import pytest
+
+import radio_mapper_amd as rm
+from oracle import xcorr_ref as orc
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def xc():
+    import __graft_entry__ as g
+    g.build()
+    from radio_mapper_amd import xcorr
+    assert xcorr.device_count() > 0, "no MI355X visible"
+    return xcorr
+
+
+def _assert_parity(li, lf, pk, ri, rf, rp, margin=None):
+    ref = ri + rf
+    got = li + lf.astype(np.float64)
+    bad = li != ri
+    if margin is not None:
+        assert not np.any(bad & (margin > TOL)), f"{int(np.sum(bad & (margin > TOL)))} integer lags differ"
+    else:
+        assert not bad.any(), f"{int(bad.sum())} integer lags differ"
+    ok = ~bad
+    assert np.all(np.abs(got[ok] - ref[ok]) <= TOL * np.maximum(np.abs(ref[ok]), 1.0)), \
+        "fractional lag outside 1e-5: max %.3e" % np.abs(got[ok] - ref[ok]).max()
+    assert np.allclose(pk[ok], rp[ok], rtol=1e-5, atol=0)
+
+
+@pytest.mark.parametrize("name", ["xcorr_b3_n4096", "xcorr_b8_n4096"])
+def test_golden_fixtures(xc, golden_dir, name):
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    iq = orc.decode_u8_iq(g["raw_u8"])
+    W, B, N = iq.shape
+    with xc.XcorrEngine(B, N, W) as eng:
+        li, lf, pk = eng.correlate(iq)
+        _assert_parity(li, lf, pk, g["lag_int"], g["lag_frac"], g["peak"], g["margin"])
+        # raw uint8 ingest (decode fused in the first kernel) must give identical results
+        li8, lf8, pk8 = eng.correlate(g["raw_u8"])
+        assert np.array_equal(li, li8) and np.array_equal(lf, lf8) and np.array_equal(pk, pk8)
+
+
+def test_edge_cases_n4096(xc):
+    """Zeros (all-tie), impulses, peaks on both edges, an exact two-peak tie, constant inputs."""
+    N = 4096
+    e = np.zeros((6, 2, N), np.complex64)
+    e[1, 0, 5] = 1.0; e[1, 1, 25] = 2.0 - 1.0j
+    e[2, 0, 0] = 3.0; e[2, 1, N - 1] = 1.0j
+    e[3, 0, N - 1] = 1.0; e[3, 1, 0] = -2.0
+    e[4, 0, 100] = 1.0; e[4, 1, 93] = 1.0; e[4, 1, 109] = 1.0
+    e[5, 0, :] = 4.5 - 2.5j; e[5, 1, :] = -1.5 + 0.5j
+    ri, rf, rp = orc.xcorr_batch_literal(e)
+    with xc.XcorrEngine(2, N, 6) as eng:
+        li, lf, pk = eng.correlate(e)
+    assert li[0, 0] == -(N - 1) and lf[0, 0] == 0.0 and pk[0, 0] == 0.0      # all ties -> lowest index
+    assert li[1, 0] == ri[1, 0] == 20
+    assert li[2, 0] == ri[2, 0] == N - 1 and lf[2, 0] == 0.0
+    assert li[3, 0] == ri[3, 0] == -(N - 1) and lf[3, 0] == 0.0
+    assert li[4, 0] in (-7, 9)              # exact tie up to FFT rounding: either candidate is a maximum
+    assert li[5, 0] == ri[5, 0] == 0 and abs(lf[5, 0] - rf[5, 0]) <= TOL
+    assert np.allclose(pk[1:], rp[1:], rtol=1e-5)
+
+
+def test_custom_pairs_and_antisymmetry(xc):
+    iq, _ = rm.synth.make_windows(16, 5, 4096, 10e6, seed=21)
+    fwd = np.array([(0, 1), (0, 4), (2, 3), (1, 4)], np.int32)
+    rev = fwd[:, ::-1].copy()
+    with xc.XcorrEngine(5, 4096, 16) as eng:
+        li, lf, pk = eng.correlate(iq, fwd)
+        ri, rf, rpk = eng.correlate(iq, rev)
+        lall, fall, pall = eng.correlate(iq)
+    # r_ji[tau] = conj(r_ij[-tau]): mirrored lag, same peak (different rounding order: 1e-5)
+    assert np.array_equal(li, -ri)
+    assert np.all(np.abs(lf + rf) <= TOL) and np.allclose(pk, rpk, rtol=1e-5)
+    allp = [tuple(p) for p in xc.pair_list(5)]
+    cols = [allp.index(tuple(p)) for p in fwd]
+    assert np.array_equal(li, lall[:, cols]) and np.array_equal(lf, fall[:, cols])
+    # against the oracle with the same custom list
+    oi, of_, op = orc.xcorr_batch_literal(iq, fwd)
+    _assert_parity(li, lf, pk, oi, of_, op)
+
+
+def test_cfg3_full_size_properties_and_subset_parity(xc):
+    """BASELINE configs[2]: B=8, N=4096, W=4096.  Size-independent properties on the full batch
+    (results do not depend on chunking / work split / window order), oracle parity on 256 windows."""
+    import torch
+    W, B, N = 4096, 8, 4096
+    iq_small, delays = rm.synth.make_windows(256, B, N, 10e6, seed=1003)
+    rng = np.random.default_rng(0)
+    reps = W // 256
+    # full batch = 16 differently rotated copies of the 256 seeded windows (rotation of every buoy by
+    # the same amount keeps the lag structure but changes all samples)
+    iq = np.empty((W, B, N), np.complex64)
+    for r in range(reps):
+        iq[r * 256:(r + 1) * 256] = iq_small if r == 0 else np.roll(iq_small, 97 * r, axis=2)
+    P = B * (B - 1) // 2
+    with xc.XcorrEngine(B, N, W) as eng:
+        a = eng.correlate(iq)
+        eng.set_option("chunk_windows", 136)
+        eng.set_option("pairs_per_block", 5)
+        b = eng.correlate(iq)
+        perm = rng.permutation(W)
+        c = eng.correlate(iq[perm])
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)                      # work decomposition never changes a bit
+    for x, y in zip(a, c):
+        assert np.array_equal(x[perm], y)                # windows are independent
+    ri, rf, rp = orc.xcorr_batch_fast(iq[:256], workers=os.cpu_count() or 1)
+    _assert_parity(a[0][:256], a[1][:256], a[2][:256], ri, rf, rp)
+    pairs = orc.pair_list(B)
+    true = delays[:, pairs[:, 1]] - delays[:, pairs[:, 0]]
+    assert np.all(np.abs(a[0][:256] + a[1][:256] - true) < 0.5)   # and the lags are the simulated ones
+    # closure on the integer-free quantity: lag(0,1) + lag(1,2) - lag(0,2) ~ 0 for a common source
+    lag = a[0] + a[1].astype(np.float64)
+    cols = {tuple(p): k for k, p in enumerate(pairs)}
+    clos = lag[:, cols[(0, 1)]] + lag[:, cols[(1, 2)]] - lag[:, cols[(0, 2)]]
+    assert np.all(np.abs(clos) < 1.0)
+
+
+def test_device_pointer_entry_and_timing(xc):
+    import torch
+    W, B, N = 64, 8, 4096
+    iq, _ = rm.synth.make_windows(W, B, N, 10e6, seed=5)
+    dev = torch.device("cuda:0")
+    x = torch.from_numpy(iq.view(np.float32).reshape(W, B, N, 2)).to(dev)
+    P = B * (B - 1) // 2
+    lag = torch.zeros((W, P), dtype=torch.int32, device=dev)
+    frac = torch.zeros((W, P), dtype=torch.float32, device=dev)
+    peak = torch.zeros((W, P), dtype=torch.float32, device=dev)
+    with xc.XcorrEngine(B, N, W) as eng:
+        eng.set_stream(torch.cuda.current_stream().cuda_stream)
+        eng.set_option("timing", 1)
+        eng.correlate_device(x.data_ptr(), W, lag.data_ptr(), frac.data_ptr(), peak.data_ptr())
+        torch.cuda.synchronize()
+        tm = eng.last_timing()
+        host = eng.correlate(iq)
+    assert tm["fwd_launches"] >= 1 and tm["pair_launches"] >= 1 and tm["pair_ms"] > 0
+    assert np.array_equal(lag.cpu().numpy(), host[0])
+    assert np.array_equal(frac.cpu().numpy(), host[1])
+    assert np.array_equal(peak.cpu().numpy(), host[2])
+
+
+def test_tdoa_processor_with_iq(xc):
+    """Drop-in API: detections that carry IQ get time differences from the GPU lag (S7)."""
+    from radio_mapper_amd import tdoa_processor as tp
+    fs = 10e6
+    iq, d = rm.synth.make_windows(1, 4, 4096, fs, seed=77)
+    proc = tp.TDoAProcessor()
+    names = ["N", "E", "S", "W"]
+    coords = [(35.50, -97.50), (35.47, -97.45), (35.44, -97.50), (35.47, -97.55)]
+    for n, (la, lo) in zip(names, coords):
+        proc.register_buoy(tp.BuoyPosition(n, la, lo, 0.0, 100))
+    t0 = 1_700_000_000_000_000_000
+    dets = [tp.SignalDetection(n, 121.5, -50.0, "t", t0, la, lo, 0.9, "emergency", iq[0, k], fs)
+            for k, (n, (la, lo)) in enumerate(zip(names, coords))]
+    meas = proc.tdoa_calculator.calculate_tdoa_measurements(dets, proc.buoy_positions)
+    oi, of_, _ = orc.xcorr_batch_literal(iq)
+    assert len(meas) == 6
+    for q, m in enumerate(meas):
+        ns, metres = orc.lag_to_tdoa(oi[0, q] + of_[0, q], fs)
+        assert abs(m.time_difference_ns - ns) <= 1
+        assert abs(m.distance_difference_m - m.time_difference_ns / 1e9 * 299792458.0) < 1e-9
