@@ -61,7 +61,12 @@ def synth_on_device(torch, dev, W, B, N, fs, seed):
 def cpu_baseline(iq_sample, budget_s=20.0):
     """The oracle (numpy/scipy restatement) timed on this box's host cores on a bounded sample."""
     from oracle import xcorr_ref as orc
-    cores = os.cpu_count() or 1
+    # threads actually used: the box's CPU share for one GPU is 16 (never the 256 logical CPUs)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except Exception:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, int(os.environ.get("RMX_CPU_THREADS", "16"))))
     W, B, N = iq_sample.shape
     P = B * (B - 1) // 2
     # variant (i): literal per-pair scipy.signal.correlate loop, one core
@@ -151,9 +156,12 @@ def main():
         # (rmx_last_timing would synchronise; it is read once per step only after the loop below)
     sync_all()
     elapsed = time.perf_counter() - t0
-    # kernel durations: re-run the same steps with event read-back (not in the timed region above)
-    for _ in range(min(args.steps, 10)):
-        step()
+    # kernel durations from the HIP events bracketing every launch on the launch stream: the last
+    # step of the timed region, then the same step repeated with a read-back after each
+    n_meas = max(min(args.steps, 10), 1)
+    for k in range(n_meas):
+        if k > 0:
+            step()
         tm = eng.last_timing()
         fwd_ms += tm["fwd_ms"]; fwd_n += tm["fwd_launches"]
         pair_ms += tm["pair_ms"]; pair_n += tm["pair_launches"]
@@ -174,7 +182,7 @@ def main():
         from oracle import xcorr_ref as orc
         nchk = min(32, W)
         iq_chk = x[:nchk].cpu().numpy().view(np.complex64).reshape(nchk, B, N)
-        ri, rf, rp = orc.xcorr_batch_fast(iq_chk, workers=os.cpu_count() or 1)
+        ri, rf, rp = orc.xcorr_batch_fast(iq_chk, workers=16)
         ref = ri + rf
         got = li[:nchk] + lf[:nchk].astype(np.float64)
         parity = {"windows": nchk, "lag_int_mismatches": int(np.sum(li[:nchk] != ri)),
@@ -188,7 +196,6 @@ def main():
         value = units_per_step / (ms_per_step * 1e-3)
         alg_bytes_per_pw = 16 * N + 12
         pair_launch_ms = pair_ms / max(pair_n, 1)
-        n_meas = max(min(args.steps, 10), 1)
         launches_per_step = max(pair_n / n_meas, 1.0)
         windows_per_launch = W / launches_per_step
         alg_bytes_per_launch = windows_per_launch * P * alg_bytes_per_pw
@@ -213,8 +220,8 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "alg_bytes_per_launch": alg_bytes_per_launch,
                          "launch_ms": pair_launch_ms,
-                         "fwd_kernel_ms_per_step": fwd_ms / max(min(args.steps, 10), 1),
-                         "pair_kernel_ms_per_step": pair_ms / max(min(args.steps, 10), 1),
+                         "fwd_kernel_ms_per_step": fwd_ms / n_meas,
+                         "pair_kernel_ms_per_step": pair_ms / n_meas,
                          "whole_path_frac": (W * P * alg_bytes_per_pw) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "cpu_baseline": cpu,
             "parity": parity,

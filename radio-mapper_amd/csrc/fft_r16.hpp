@@ -103,10 +103,17 @@ __device__ __forceinline__ float2 w32(int q) {
     return make_float2(c[q], -s[q]);
 }
 
-// ---- LDS exchanges (complex index into a float2 array of kL entries) -------------------------
-// A<->B image: idx = k0*512 + ((n1*16 + n0)*2 + p).  Role-A lanes are contiguous in it for a fixed
-// slot k0; role-B lanes (k0 lowbit, n0, p within a wave) read one contiguous 256-B run per 32-lane
-// half for a fixed slot n1: conflict free both ways.
+// ---- LDS exchanges (complex index into a float2 array of kXchgF2 entries) -----------------------
+// Both images give half wave k0 (32 lanes: fixed k0 in roles B and C) the SAME private region
+// [k0*kBcHalf, (k0+1)*kBcHalf): a wave only ever overwrites LDS that itself (or nobody) still
+// needs, so the only workgroup barrier of an exchange is the one between A-side and B-side accesses.
+// A<->B image: idx = k0*kBcHalf + ((n1*16 + n0)*2 + p).  Role-A lanes are contiguous in it for a
+// fixed slot k0; role-B lanes read/write one contiguous 256-B run per 32-lane half for a fixed slot
+// n1: conflict free both ways.
+constexpr int kBcRow = 34;
+constexpr int kBcHalf = 16 * kBcRow;          // complex per half wave (>= 512)
+constexpr int kXchgF2 = 16 * kBcHalf;         // complex in the whole exchange image
+
 __device__ __forceinline__ void wave_lds_fence() {
     // orders this wave's LDS writes before its later LDS reads (same-wave exchange, no barrier)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -117,33 +124,30 @@ __device__ __forceinline__ void wave_lds_fence() {
 
 __device__ __forceinline__ void xchg_a_write(float2* lds, const float2 (&v)[16], int t) {
 #pragma unroll
-    for (int k0 = 0; k0 < 16; ++k0) lds[k0 * 512 + t] = v[k0];
+    for (int k0 = 0; k0 < 16; ++k0) lds[k0 * kBcHalf + t] = v[k0];
 }
 __device__ __forceinline__ void xchg_a_read(const float2* lds, float2 (&v)[16], int t) {
 #pragma unroll
-    for (int k0 = 0; k0 < 16; ++k0) v[k0] = lds[k0 * 512 + t];
+    for (int k0 = 0; k0 < 16; ++k0) v[k0] = lds[k0 * kBcHalf + t];
 }
 // role B thread: u = 16*k0 + n0; slot = n1
 __device__ __forceinline__ void xchg_b_write(float2* lds, const float2 (&v)[16], int t) {
     const int p = t & 1, u = t >> 1, k0 = u >> 4, n0 = u & 15;
-    const int base = k0 * 512 + n0 * 2 + p;
+    float2* base = lds + k0 * kBcHalf + n0 * 2 + p;
 #pragma unroll
-    for (int n1 = 0; n1 < 16; ++n1) lds[base + n1 * 32] = v[n1];
+    for (int n1 = 0; n1 < 16; ++n1) base[n1 * 32] = v[n1];
 }
 __device__ __forceinline__ void xchg_b_read(const float2* lds, float2 (&v)[16], int t) {
     const int p = t & 1, u = t >> 1, k0 = u >> 4, n0 = u & 15;
-    const int base = k0 * 512 + n0 * 2 + p;
+    const float2* base = lds + k0 * kBcHalf + n0 * 2 + p;
 #pragma unroll
-    for (int n1 = 0; n1 < 16; ++n1) v[n1] = lds[base + n1 * 32];
+    for (int n1 = 0; n1 < 16; ++n1) v[n1] = base[n1 * 32];
 }
 // B<->C image (inside one half wave, fixed k0): idx = k0*kBcHalf + k1*kBcRow + 2*n0 + p with rows of
 // 32 complex padded to 34.  Role B (a = n0, slot k1) touches 32 contiguous complex per access; role
 // C (a = k1, slot n0) touches 16 rows 34 complex apart, i.e. 16 distinct 16-B bank groups (68*a mod
 // 64 = 4*a): conflict free both ways, and every slot is base + immediate offset (no per-slot
 // address registers).
-constexpr int kBcRow = 34;
-constexpr int kBcHalf = 16 * kBcRow;          // complex per half wave
-constexpr int kXchgF2 = 16 * kBcHalf;         // complex in the whole exchange image (>= kL)
 __device__ __forceinline__ void xchg_bc_write_b(float2* lds, const float2 (&v)[16], int t) {
     const int p = t & 1, u = t >> 1, k0 = u >> 4, a = u & 15;
     float2* base = lds + k0 * kBcHalf + 2 * a + p;

@@ -96,8 +96,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_fwd(const void* __restrict__ iq
     xchg_b_read(xl, v, t);
     dft16(v);                         // n1 -> k1
     mul_tw2(v, tw2_lds, u & 15);      // W_256^(n0*k1)
-    __syncthreads();                  // every wave is done reading the A<->B image
-    xchg_bc_write_b(xl, v, t);
+    xchg_bc_write_b(xl, v, t);        // own half-wave region: no barrier
     wave_lds_fence();
     xchg_bc_read_c(xl, v, t);
     dft16(v);                         // n0 -> k2
@@ -111,15 +110,16 @@ __global__ __launch_bounds__(kThreads, 4) void k_fwd(const void* __restrict__ iq
 // ------------------------------------------------------------------------------------------------
 // Pair kernel.  grid = n_windows_in_chunk * n_parts; each workgroup walks items[part_begin..end).
 //   out arrays are indexed [(first_window + wl) * n_pairs + item.out].
-__global__ __launch_bounds__(kThreads, 4) void k_pair(const float4* __restrict__ spec,
-                                                      const float4* __restrict__ tw1_g,
-                                                      const float2* __restrict__ tw2_g,
-                                                      const PairItem* __restrict__ items,
-                                                      const int* __restrict__ part_begin, int n_parts,
-                                                      int n_buoys, int n_pairs, int n_win, int xcd_map,
-                                                      long first_window, float out_scale,
-                                                      int* __restrict__ lag_int, float* __restrict__ lag_frac,
-                                                      float* __restrict__ peak) {
+// RESIDENT = true : one workgroup per CU (<= 256 VGPRs): TW1 and the anchor spectrum X_i stay in
+//                   registers across pairs; only X_j streams, requested one whole pair ahead.
+// RESIDENT = false: two workgroups per CU (<= 128 VGPRs): TW1 and X_i are re-read every pair.
+template <bool RESIDENT>
+__device__ __forceinline__ void pair_body(const float4* __restrict__ spec, const float4* __restrict__ tw1_g,
+                                          const float2* __restrict__ tw2_g, const PairItem* __restrict__ items,
+                                          const int* __restrict__ part_begin, int n_parts, int n_buoys,
+                                          int n_pairs, int xcd_map, long first_window, float out_scale,
+                                          int* __restrict__ lag_int, float* __restrict__ lag_frac,
+                                          float* __restrict__ peak) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2* xl = reinterpret_cast<float2*>(smem);
     float2* tw2_lds = reinterpret_cast<float2*>(smem + kLdsXchg);
@@ -146,18 +146,19 @@ __global__ __launch_bounds__(kThreads, 4) void k_pair(const float4* __restrict__
             part = b % n_parts;
         }
     }
-    (void)n_win;
 
     load_tw2_to_lds(tw2_lds, tw2_g, t);
+    float2 tw1r[16];
+    if constexpr (RESIDENT) load_tw1(tw1r, tw1_g, t);
     __syncthreads();
 
     const float sgn = p ? -1.0f : 1.0f;
     const int it_begin = part_begin[part];
     const int it_end = part_begin[part + 1];
     const long wbase = (long)wl * n_buoys;
-    // software pipeline: the spectra of pair it+1 are requested while pair it is being reduced
-    float4 sa[8], sb[8];
+    float4 sa[8], sb[8];   // X_i (anchor) and X_j of the pair about to be processed
     PairItem pi = items[it_begin < it_end ? it_begin : 0];
+    int cur_i = pi.i;
     if (it_begin < it_end) {
         const float4* xi = spec + (wbase + pi.i) * (8 * kThreads);
         const float4* xj = spec + (wbase + pi.j) * (8 * kThreads);
@@ -179,25 +180,39 @@ __global__ __launch_bounds__(kThreads, 4) void k_pair(const float4* __restrict__
             v[2 * j] = make_float2(b.y * a.x - b.x * a.y, b.x * a.x + b.y * a.y);
             v[2 * j + 1] = make_float2(b.w * a.z - b.z * a.w, b.z * a.z + b.w * a.w);
         }
+        if constexpr (RESIDENT) {
+            // request the next pair's spectra now: a whole pair of compute hides the latency
+            if (it + 1 < it_end) {
+                pi = items[it + 1];
+                const float4* xj = spec + (wbase + pi.j) * (8 * kThreads);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sb[j] = xj[j * kThreads + t];
+                if (pi.i != cur_i) {
+                    cur_i = pi.i;
+                    const float4* xi = spec + (wbase + pi.i) * (8 * kThreads);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) sa[j] = xi[j * kThreads + t];
+                }
+            }
+        }
         dft16(v);                     // k2 -> n0   (role C)
         mul_tw2(v, tw2_lds, u & 15);  // W_256^(k1*n0)
         xchg_bc_write_c(xl, v, t);
         wave_lds_fence();
         xchg_bc_read_b(xl, v, t);
         dft16(v);                     // k1 -> n1   (role B)
-        // TW1 is re-read every pair (64 KiB per workgroup from L2) instead of living in 32 VGPRs;
-        // the pointer is laundered so that the loads stay here, in flight across the exchange.
-        float2 tw1[16];
-        {
+        float2 tw1s[16];
+        if constexpr (!RESIDENT) {
+            // TW1 re-read every pair (64 KiB per workgroup from L2); the pointer is laundered so
+            // that the loads stay here, in flight across the exchange.
             const float4* twp = tw1_g;
             asm volatile("" : "+s"(twp));
-            load_tw1(tw1, twp, t);
+            load_tw1(tw1s, twp, t);
         }
-        __syncthreads();              // all waves finished with their B<->C slices
-        xchg_b_write(xl, v, t);
+        xchg_b_write(xl, v, t);       // into this half wave's own region: no barrier needed before
         __syncthreads();
         xchg_a_read(xl, v, t);
-        mul_tw1(v, tw1);              // W_M^(u*k0) [* W_L^u on odd lanes]
+        if constexpr (RESIDENT) mul_tw1(v, tw1r); else mul_tw1(v, tw1s);   // W_M^(u*k0) [* W_L^u odd]
         dft16(v);                     // k0 -> n2   (role A): lane holds e[n] (p=0) or o[n]*W_L^u (p=1)
         if (p) {
 #pragma unroll
@@ -211,18 +226,20 @@ __global__ __launch_bounds__(kThreads, 4) void k_pair(const float4* __restrict__
             const float ry = sgn * v[q].y + dpp_xor1(v[q].y);
             mag[q] = rx * rx + ry * ry;
         }
-        // 'full' order index of slot q: even lanes lag tau = n >= 0 -> k = n + M - 1;
-        // odd lanes tau = n - M -> k = n - 1 (n = 0, i.e. tau = -M, is not part of 'full').
-        if (it + 1 < it_end) {
-            pi = items[it + 1];
-            const float4* xi = spec + (wbase + pi.i) * (8 * kThreads);
-            const float4* xj = spec + (wbase + pi.j) * (8 * kThreads);
+        if constexpr (!RESIDENT) {
+            if (it + 1 < it_end) {
+                pi = items[it + 1];
+                const float4* xi = spec + (wbase + pi.i) * (8 * kThreads);
+                const float4* xj = spec + (wbase + pi.j) * (8 * kThreads);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                sa[j] = xi[j * kThreads + t];
-                sb[j] = xj[j * kThreads + t];
+                for (int j = 0; j < 8; ++j) {
+                    sa[j] = xi[j * kThreads + t];
+                    sb[j] = xj[j * kThreads + t];
+                }
             }
         }
+        // 'full' order index of slot q: even lanes lag tau = n >= 0 -> k = n + M - 1;
+        // odd lanes tau = n - M -> k = n - 1 (n = 0, i.e. tau = -M, is not part of 'full').
         if (p && u == 0) mag[0] = -1.0f;
         float tmax = mag[0];
 #pragma unroll
@@ -280,6 +297,18 @@ __global__ __launch_bounds__(kThreads, 4) void k_pair(const float4* __restrict__
     }
 }
 
+#define RMX_PAIR_ARGS                                                                                         \
+    const float4 *__restrict__ spec, const float4 *__restrict__ tw1_g, const float2 *__restrict__ tw2_g,      \
+        const PairItem *__restrict__ items, const int *__restrict__ part_begin, int n_parts, int n_buoys,     \
+        int n_pairs, int xcd_map, long first_window, float out_scale, int *__restrict__ lag_int,              \
+        float *__restrict__ lag_frac, float *__restrict__ peak
+#define RMX_PAIR_PASS                                                                                         \
+    spec, tw1_g, tw2_g, items, part_begin, n_parts, n_buoys, n_pairs, xcd_map, first_window, out_scale,      \
+        lag_int, lag_frac, peak
+
+__global__ __launch_bounds__(kThreads, 2) void k_pair_res(RMX_PAIR_ARGS) { pair_body<true>(RMX_PAIR_PASS); }
+__global__ __launch_bounds__(kThreads, 4) void k_pair_str(RMX_PAIR_ARGS) { pair_body<false>(RMX_PAIR_PASS); }
+
 // ================================================================================================
 // host side
 // ================================================================================================
@@ -295,6 +324,7 @@ struct rmx_ctx {
     int chunk_windows = 0;
     int pairs_per_block = 7;
     bool timing = false;
+    bool resident = true;   // pair kernel variant: 1 workgroup/CU with resident tables
     // device buffers
     float4* d_spec = nullptr;
     float4* d_tw1 = nullptr;
@@ -474,7 +504,8 @@ int rmx_create(rmx_ctx** out, int device_id, int n_buoys, int n_samples, int max
         c->scratch_bytes = c->spec_bytes + tw1.size() * sizeof(float4) + tw2.size() * sizeof(float2);
         RMX_HIP(c, hipFuncSetAttribute((const void*)k_fwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
         RMX_HIP(c, hipFuncSetAttribute((const void*)k_fwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
-        RMX_HIP(c, hipFuncSetAttribute((const void*)k_pair, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+        RMX_HIP(c, hipFuncSetAttribute((const void*)k_pair_res, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+        RMX_HIP(c, hipFuncSetAttribute((const void*)k_pair_str, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
         return RMX_OK;
     };
     rc = init();
@@ -534,6 +565,10 @@ int rmx_set_option(rmx_ctx* c, const char* key, long value) {
     if (!strcmp(key, "pairs_per_block")) {
         if (value < 1 || value > 1 << 20) return fail(c, RMX_E_INVAL, "pairs_per_block %ld out of range", value);
         c->pairs_per_block = (int)value;
+        return RMX_OK;
+    }
+    if (!strcmp(key, "resident")) {
+        c->resident = value != 0;
         return RMX_OK;
     }
     if (!strcmp(key, "timing")) {
@@ -628,9 +663,14 @@ int rmx_xcorr_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pa
             RMX_HIP(c, hipEventRecord(c->ev[c->ev_used], c->stream));
         }
         const int xcd_map = (wc % 8 == 0) ? 1 : 0;
-        hipLaunchKernelGGL(k_pair, dim3(wc * n_parts), dim3(kThreads), kLdsBytes, c->stream, c->d_spec, c->d_tw1,
-                           c->d_tw2, c->d_items, c->d_part_begin, n_parts, c->n_buoys, n_pairs, wc, xcd_map,
-                           (long)w0, out_scale, d_lag, d_frac, d_peak);
+        if (c->resident)
+            hipLaunchKernelGGL(k_pair_res, dim3(wc * n_parts), dim3(kThreads), kLdsBytes, c->stream, c->d_spec,
+                               c->d_tw1, c->d_tw2, c->d_items, c->d_part_begin, n_parts, c->n_buoys, n_pairs,
+                               xcd_map, (long)w0, out_scale, d_lag, d_frac, d_peak);
+        else
+            hipLaunchKernelGGL(k_pair_str, dim3(wc * n_parts), dim3(kThreads), kLdsBytes, c->stream, c->d_spec,
+                               c->d_tw1, c->d_tw2, c->d_items, c->d_part_begin, n_parts, c->n_buoys, n_pairs,
+                               xcd_map, (long)w0, out_scale, d_lag, d_frac, d_peak);
         RMX_HIP(c, hipGetLastError());
         if (c->timing) {
             RMX_HIP(c, hipEventRecord(c->ev[c->ev_used + 1], c->stream));

@@ -112,20 +112,22 @@ def test_cfg3_full_size_properties_and_subset_parity(xc):
         a = eng.correlate(iq)
         eng.set_option("chunk_windows", 136)
         eng.set_option("pairs_per_block", 5)
+        eng.set_option("resident", 0)
         b = eng.correlate(iq)
+        eng.set_option("resident", 1)
         perm = rng.permutation(W)
         c = eng.correlate(iq[perm])
     for x, y in zip(a, b):
         assert np.array_equal(x, y)                      # work decomposition never changes a bit
     for x, y in zip(a, c):
         assert np.array_equal(x[perm], y)                # windows are independent
-    ri, rf, rp = orc.xcorr_batch_fast(iq[:256], workers=os.cpu_count() or 1)
+    ri, rf, rp = orc.xcorr_batch_fast(iq[:256], workers=16)
     _assert_parity(a[0][:256], a[1][:256], a[2][:256], ri, rf, rp)
     pairs = orc.pair_list(B)
     true = delays[:, pairs[:, 1]] - delays[:, pairs[:, 0]]
     assert np.all(np.abs(a[0][:256] + a[1][:256] - true) < 0.5)   # and the lags are the simulated ones
     # closure on the integer-free quantity: lag(0,1) + lag(1,2) - lag(0,2) ~ 0 for a common source
-    lag = a[0] + a[1].astype(np.float64)
+    lag = a[0][:256] + a[1][:256].astype(np.float64)
     cols = {tuple(p): k for k, p in enumerate(pairs)}
     clos = lag[:, cols[(0, 1)]] + lag[:, cols[(1, 2)]] - lag[:, cols[(0, 2)]]
     assert np.all(np.abs(clos) < 1.0)

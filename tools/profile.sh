@@ -1,0 +1,19 @@
+#!/bin/bash
+# Profiling recipe for the GPU box (run through gpurun from the repo root):
+#   tools/profile.sh <tag>     -> gpurun_out/prof_<tag>/{stats,pmc_*}  (copy summaries into profiles/)
+# Kernel-trace/stats and every PMC set are separate rocprofv3 runs (never combined).
+set -o pipefail
+tag=${1:-r01}
+out=$PWD/gpurun_out/prof_$tag
+mkdir -p "$out"
+export TMPDIR=/tmp
+BENCH="python3 $PWD/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+cd /tmp
+rocprofv3 --kernel-trace --stats -T -f csv -d "$out/stats" -o stats -- $BENCH > "$out/stats.log" 2>&1 || echo "stats run failed"
+for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_ACTIVE_INST_VALU" \
+           "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU" \
+           "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum"; do
+  name=$(echo $set | tr ' ' '_' | cut -c1-40)
+  rocprofv3 --pmc $set -T -f csv -d "$out/pmc_$name" -o pmc -- $BENCH > "$out/pmc_$name.log" 2>&1 || echo "pmc $name failed"
+done
+ls -R "$out" | head -50
