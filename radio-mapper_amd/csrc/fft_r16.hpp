@@ -196,4 +196,29 @@ __device__ __forceinline__ float dpp_xor1(float x) {
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));
 }
 
+// ---- wave64 reductions on the VALU (DPP row ops + 4 readlanes; no LDS traffic) -------------------
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int x) { return __builtin_amdgcn_update_dpp(x, x, CTRL, 0xF, 0xF, false); }
+__device__ __forceinline__ float wave_max_f32(float x) {
+    x = fmaxf(x, __builtin_bit_cast(float, dpp_i<0xB1>(__builtin_bit_cast(int, x))));   // quad_perm [1,0,3,2]
+    x = fmaxf(x, __builtin_bit_cast(float, dpp_i<0x4E>(__builtin_bit_cast(int, x))));   // quad_perm [2,3,0,1]
+    x = fmaxf(x, __builtin_bit_cast(float, dpp_i<0x141>(__builtin_bit_cast(int, x))));  // row_half_mirror
+    x = fmaxf(x, __builtin_bit_cast(float, dpp_i<0x140>(__builtin_bit_cast(int, x))));  // row_mirror
+    const int xi = __builtin_bit_cast(int, x);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+__device__ __forceinline__ int wave_min_i32(int x) {
+    x = min(x, dpp_i<0xB1>(x));
+    x = min(x, dpp_i<0x4E>(x));
+    x = min(x, dpp_i<0x141>(x));
+    x = min(x, dpp_i<0x140>(x));
+    const int r0 = __builtin_amdgcn_readlane(x, 0), r1 = __builtin_amdgcn_readlane(x, 16);
+    const int r2 = __builtin_amdgcn_readlane(x, 32), r3 = __builtin_amdgcn_readlane(x, 48);
+    return min(min(r0, r1), min(r2, r3));
+}
+
 }  // namespace rmx

@@ -297,6 +297,174 @@ __device__ __forceinline__ void pair_body(const float4* __restrict__ spec, const
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Resident pair kernel (one workgroup per CU, <= 256 VGPRs).  One workgroup barrier per pair:
+//   pair n:  product -> [request X_j of pair n+1] -> DFT16 -> TW2 -> wave-local exchange -> DFT16 ->
+//            write A<->B image -> BARRIER -> [resolve pair n-1] -> read image -> TW1 -> DFT16 -> W32 ->
+//            lane-pair butterfly, |.|^2 -> publish: all |.|^2 to an LDS tap buffer, wave winner
+//            (max, lowest 'full' index) to an LDS slot.
+// The cross-wave part of the argmax and the 3-tap parabola of pair n are "resolved" by one lane
+// after the barrier of pair n+1 (both LDS buffers are double buffered by pair parity), so the
+// reduction's latency chain hides behind the next pair's arithmetic.
+constexpr int kLdsMag = kL * 4;                         // one |.|^2 image: [q4][t] float4
+constexpr int kLdsResOff = kLdsXchg + kLdsTw2;
+constexpr int kLdsResBytes = kLdsXchg + kLdsTw2 + 2 * kLdsMag + 256;
+
+__device__ __forceinline__ void resolve_pair(const float* magbuf, const float2* red, long out_pos, float out_scale,
+                                             int* __restrict__ lag_int, float* __restrict__ lag_frac,
+                                             float* __restrict__ peak) {
+    // red[w] = (wave max of |r|^2 as float bits, lowest 'full' index attaining it), w = 0..7
+    float gmax = -2.0f;
+    int kstar = 0x7fffffff;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        const float2 e = red[w];
+        const float m = e.x;
+        const int k = __builtin_bit_cast(int, e.y);
+        if (m > gmax || (m == gmax && k < kstar)) { gmax = m; kstar = k; }
+    }
+    auto tap = [&](int kk) -> float {
+        const int par = (kk >= kM - 1) ? 0 : 1;
+        const int n = par ? (kk + 1) : (kk - (kM - 1));
+        const int tt = 2 * (n & 255) + par, q = n >> 8;
+        return sqrtf(magbuf[((q >> 2) * kThreads + tt) * 4 + (q & 3)]) * out_scale;
+    };
+    const float b = sqrtf(gmax) * out_scale;
+    float frac = 0.0f;
+    if (kstar > 0 && kstar < 2 * kM - 2) {
+        const float a = tap(kstar - 1), c = tap(kstar + 1);
+        const double den = (double)a - 2.0 * (double)b + (double)c;
+        if (den != 0.0) frac = (float)(0.5 * ((double)a - (double)c) / den);
+    }
+    lag_int[out_pos] = kstar - (kM - 1);
+    lag_frac[out_pos] = frac;
+    peak[out_pos] = b;
+}
+
+__global__ __launch_bounds__(kThreads, 2) void k_pair_res(
+    const float4* __restrict__ spec, const float4* __restrict__ tw1_g, const float2* __restrict__ tw2_g,
+    const PairItem* __restrict__ items, const int* __restrict__ part_begin, int n_parts, int n_buoys, int n_pairs,
+    int xcd_map, long first_window, float out_scale, int* __restrict__ lag_int, float* __restrict__ lag_frac,
+    float* __restrict__ peak) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2* xl = reinterpret_cast<float2*>(smem);
+    float2* tw2_lds = reinterpret_cast<float2*>(smem + kLdsXchg);
+    float4* magbuf = reinterpret_cast<float4*>(smem + kLdsResOff);                 // [2][4][512] float4
+    float2* red = reinterpret_cast<float2*>(smem + kLdsResOff + 2 * kLdsMag);      // [2][8]
+
+    const int t = threadIdx.x;
+    const int p = t & 1, u = t >> 1;
+    const int lane = t & 63, wave = t >> 6;
+    int wl, part;
+    {
+        const int b = blockIdx.x;
+        if (xcd_map) {
+            const int xcd = b & 7, s = b >> 3;
+            wl = (s / n_parts) * 8 + xcd;
+            part = s % n_parts;
+        } else {
+            wl = b / n_parts;
+            part = b % n_parts;
+        }
+    }
+    load_tw2_to_lds(tw2_lds, tw2_g, t);
+    float2 tw1[16];
+    load_tw1(tw1, tw1_g, t);
+    __syncthreads();
+
+    const float sgn = p ? -1.0f : 1.0f;
+    const int kbase = p ? (u - 1) : (u + kM - 1);
+    const int it_begin = part_begin[part];
+    const int it_end = part_begin[part + 1];
+    if (it_begin >= it_end) return;
+    const long wbase = (long)wl * n_buoys;
+    const long obase = (first_window + wl) * (long)n_pairs;
+    float4 sa[8], sb[8];
+    PairItem pi = items[it_begin];
+    int cur_i = pi.i;
+    {
+        const float4* xi = spec + (wbase + pi.i) * (8 * kThreads);
+        const float4* xj = spec + (wbase + pi.j) * (8 * kThreads);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            sa[j] = xi[j * kThreads + t];
+            sb[j] = xj[j * kThreads + t];
+        }
+    }
+    int prev_out = -1;
+    for (int it = it_begin; it < it_end; ++it) {
+        const int out_idx = pi.out;
+        const int buf = (it - it_begin) & 1;
+        float2 v[16];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float4 a = sa[j];
+            const float4 b = sb[j];
+            v[2 * j] = make_float2(b.y * a.x - b.x * a.y, b.x * a.x + b.y * a.y);
+            v[2 * j + 1] = make_float2(b.w * a.z - b.z * a.w, b.z * a.z + b.w * a.w);
+        }
+        if (it + 1 < it_end) {   // request the next pair's spectra: a whole pair of compute hides it
+            pi = items[it + 1];
+            const float4* xj = spec + (wbase + pi.j) * (8 * kThreads);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sb[j] = xj[j * kThreads + t];
+            if (pi.i != cur_i) {
+                cur_i = pi.i;
+                const float4* xi = spec + (wbase + pi.i) * (8 * kThreads);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sa[j] = xi[j * kThreads + t];
+            }
+        }
+        dft16(v);                     // k2 -> n0   (role C)
+        mul_tw2(v, tw2_lds, u & 15);  // W_256^(k1*n0)
+        xchg_bc_write_c(xl, v, t);
+        wave_lds_fence();
+        xchg_bc_read_b(xl, v, t);
+        dft16(v);                     // k1 -> n1   (role B)
+        xchg_b_write(xl, v, t);       // into this half wave's own region
+        __syncthreads();              // the pair's only barrier; also publishes pair it-1's winners
+        if (prev_out >= 0 && t == ((it - it_begin) & 7) * 64)
+            resolve_pair(reinterpret_cast<const float*>(magbuf + (buf ^ 1) * (4 * kThreads)), red + (buf ^ 1) * 8,
+                         obase + prev_out, out_scale, lag_int, lag_frac, peak);
+        xchg_a_read(xl, v, t);
+        mul_tw1(v, tw1);              // W_M^(u*k0) [* W_L^u on odd lanes]
+        dft16(v);                     // k0 -> n2   (role A): e[n] (even lanes) / o[n]*W_L^u (odd lanes)
+        if (p) {
+#pragma unroll
+            for (int q = 1; q < 16; ++q) v[q] = cmul(v[q], w32(q));
+        }
+        float mag[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float rx = sgn * v[q].x + dpp_xor1(v[q].x);
+            const float ry = sgn * v[q].y + dpp_xor1(v[q].y);
+            mag[q] = rx * rx + ry * ry;
+        }
+        if (p && u == 0) mag[0] = -1.0f;   // lag -M is not part of the 'full' output
+        float4* mb = magbuf + buf * (4 * kThreads) + t;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4)
+            mb[q4 * kThreads] = make_float4(mag[4 * q4], mag[4 * q4 + 1], mag[4 * q4 + 2], mag[4 * q4 + 3]);
+        float tmax = mag[0];
+#pragma unroll
+        for (int q = 1; q < 16; ++q) tmax = fmaxf(tmax, mag[q]);
+        int kq = 0;
+#pragma unroll
+        for (int q = 15; q >= 0; --q)
+            if (mag[q] == tmax) kq = kbase + q * 256;   // lowest 'full' index of this lane's maximum
+        const float wmax = wave_max_f32(tmax);
+        const int kw = wave_min_i32(tmax == wmax ? kq : 0x7fffffff);
+        if (lane == 0) red[buf * 8 + wave] = make_float2(wmax, __builtin_bit_cast(float, kw));
+        prev_out = out_idx;
+    }
+    __syncthreads();
+    if (t == 0) {
+        const int buf = (it_end - 1 - it_begin) & 1;
+        resolve_pair(reinterpret_cast<const float*>(magbuf + buf * (4 * kThreads)), red + buf * 8, obase + prev_out,
+                     out_scale, lag_int, lag_frac, peak);
+    }
+}
+
 #define RMX_PAIR_ARGS                                                                                         \
     const float4 *__restrict__ spec, const float4 *__restrict__ tw1_g, const float2 *__restrict__ tw2_g,      \
         const PairItem *__restrict__ items, const int *__restrict__ part_begin, int n_parts, int n_buoys,     \
@@ -306,7 +474,6 @@ __device__ __forceinline__ void pair_body(const float4* __restrict__ spec, const
     spec, tw1_g, tw2_g, items, part_begin, n_parts, n_buoys, n_pairs, xcd_map, first_window, out_scale,      \
         lag_int, lag_frac, peak
 
-__global__ __launch_bounds__(kThreads, 2) void k_pair_res(RMX_PAIR_ARGS) { pair_body<true>(RMX_PAIR_PASS); }
 __global__ __launch_bounds__(kThreads, 4) void k_pair_str(RMX_PAIR_ARGS) { pair_body<false>(RMX_PAIR_PASS); }
 
 // ================================================================================================
@@ -504,7 +671,7 @@ int rmx_create(rmx_ctx** out, int device_id, int n_buoys, int n_samples, int max
         c->scratch_bytes = c->spec_bytes + tw1.size() * sizeof(float4) + tw2.size() * sizeof(float2);
         RMX_HIP(c, hipFuncSetAttribute((const void*)k_fwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
         RMX_HIP(c, hipFuncSetAttribute((const void*)k_fwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
-        RMX_HIP(c, hipFuncSetAttribute((const void*)k_pair_res, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+        RMX_HIP(c, hipFuncSetAttribute((const void*)k_pair_res, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsResBytes));
         RMX_HIP(c, hipFuncSetAttribute((const void*)k_pair_str, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
         return RMX_OK;
     };
@@ -664,7 +831,7 @@ int rmx_xcorr_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pa
         }
         const int xcd_map = (wc % 8 == 0) ? 1 : 0;
         if (c->resident)
-            hipLaunchKernelGGL(k_pair_res, dim3(wc * n_parts), dim3(kThreads), kLdsBytes, c->stream, c->d_spec,
+            hipLaunchKernelGGL(k_pair_res, dim3(wc * n_parts), dim3(kThreads), kLdsResBytes, c->stream, c->d_spec,
                                c->d_tw1, c->d_tw2, c->d_items, c->d_part_begin, n_parts, c->n_buoys, n_pairs,
                                xcd_map, (long)w0, out_scale, d_lag, d_frac, d_peak);
         else

@@ -112,13 +112,14 @@ def test_cfg3_full_size_properties_and_subset_parity(xc):
         a = eng.correlate(iq)
         eng.set_option("chunk_windows", 136)
         eng.set_option("pairs_per_block", 5)
-        eng.set_option("resident", 0)
         b = eng.correlate(iq)
-        eng.set_option("resident", 1)
         perm = rng.permutation(W)
         c = eng.correlate(iq[perm])
+        eng.set_option("resident", 0)                    # the 2-workgroups-per-CU kernel variant
+        d = eng.correlate(iq[:512])
     for x, y in zip(a, b):
         assert np.array_equal(x, y)                      # work decomposition never changes a bit
+    _assert_parity(d[0], d[1], d[2], a[0][:512], a[1][:512].astype(np.float64), a[2][:512])
     for x, y in zip(a, c):
         assert np.array_equal(x[perm], y)                # windows are independent
     ri, rf, rp = orc.xcorr_batch_fast(iq[:256], workers=16)

@@ -63,7 +63,8 @@ def timing(W=4096, B=8, N=4096, chunk=None, ppb=None, reps=5, resident=1):
 if __name__ == "__main__":
     print("lib:", xcorr.library_path(), "devices:", xcorr.device_count())
     parity()
-    for res in (1, 0):
-        for ppb in (7, 4, 2):
+    for res in (1,):
+        for ppb in (7, 4, 14):
             for chunk in (512, 4096):
                 timing(chunk=chunk, ppb=ppb, resident=res)
+    timing(chunk=4096, ppb=7, resident=0)
