@@ -58,23 +58,57 @@ __device__ __forceinline__ float2 mul_w16(float2 a) {
     else return a;
 }
 
-// 16-point DFT, X[k] = sum_q v[q] W16^(qk), natural order in, natural order out.
-__device__ __forceinline__ void dft16(float2 (&v)[16]) {
-    // q = 4*q1 + q0, k = ka + 4*kb.  Step 1: DFT4 over q1 for each q0 -> y[q0][ka] in v[q0+4ka].
-    dft4(v[0], v[4], v[8], v[12]);
-    dft4(v[1], v[5], v[9], v[13]);
-    dft4(v[2], v[6], v[10], v[14]);
-    dft4(v[3], v[7], v[11], v[15]);
-    // Step 2: y[q0][ka] *= W16^(q0*ka)
-    v[5] = mul_w16<1>(v[5]);   v[6] = mul_w16<2>(v[6]);    v[7] = mul_w16<3>(v[7]);
-    v[9] = mul_w16<2>(v[9]);   v[10] = mul_w16<4>(v[10]);  v[11] = mul_w16<6>(v[11]);
-    v[13] = mul_w16<3>(v[13]); v[14] = mul_w16<6>(v[14]);  v[15] = mul_w16<9>(v[15]);
-    // Step 3: DFT4 over q0 for each ka -> X[ka + 4kb] lands in v[4ka + kb]
-    dft4(v[0], v[1], v[2], v[3]);
-    dft4(v[4], v[5], v[6], v[7]);
-    dft4(v[8], v[9], v[10], v[11]);
-    dft4(v[12], v[13], v[14], v[15]);
-    // un-transpose (pure register renaming)
+// acc + a*w (4 FMAs)
+__device__ __forceinline__ float2 cfma(float2 acc, float2 a, float2 w) {
+    float re = fmaf(a.x, w.x, acc.x);
+    re = fmaf(-a.y, w.y, re);
+    float im = fmaf(a.x, w.y, acc.y);
+    im = fmaf(a.y, w.x, im);
+    return make_float2(re, im);
+}
+// 2*a - b (1 FMA per component): the second output of a twiddled radix-2 butterfly,
+// t1 = A - w*s = 2A - (A + w*s), costs 2 instead of 4 instructions.
+__device__ __forceinline__ float2 twice_minus(float2 a, float2 b) {
+    return make_float2(fmaf(2.0f, a.x, -b.x), fmaf(2.0f, a.y, -b.y));
+}
+__device__ __forceinline__ void dft4_tail(float2& a0, float2& a1, float2& a2, float2& a3, float2 t0, float2 t1,
+                                          float2 t2, float2 t3) {
+    a0 = cadd(t0, t2);
+    a2 = csub(t0, t2);
+    a1 = make_float2(t1.x + t3.y, t1.y - t3.x);  // t1 - i*t3
+    a3 = make_float2(t1.x - t3.y, t1.y + t3.x);  // t1 + i*t3
+}
+// DFT4 of (w0*a0, w1*a1, w2*a2, w3*a3): pre-twiddles merged into the first butterfly layer
+// (28 instructions instead of 16 + 16; 24 when w0 == 1).
+template <bool W0_IS_ONE>
+__device__ __forceinline__ void dft4_tw(float2& a0, float2& a1, float2& a2, float2& a3, float2 w0, float2 w1,
+                                        float2 w2, float2 w3) {
+    const float2 A0 = W0_IS_ONE ? a0 : cmul(a0, w0);
+    const float2 t0 = cfma(A0, a2, w2);
+    const float2 t1 = twice_minus(A0, t0);
+    const float2 A1 = cmul(a1, w1);
+    const float2 t2 = cfma(A1, a3, w3);
+    const float2 t3 = twice_minus(A1, t2);
+    dft4_tail(a0, a1, a2, a3, t0, t1, t2, t3);
+}
+
+// second radix-4 layer of the 16-point DFT with its constant inner twiddles W16^(q0*ka) merged
+__device__ __forceinline__ void dft16_layer2(float2 (&v)[16]) {
+    dft4(v[0], v[1], v[2], v[3]);                                                  // ka = 0
+    dft4_tw<true>(v[4], v[5], v[6], v[7], make_float2(1.f, 0.f), make_float2(RMX_C1, -RMX_S1),
+                  make_float2(RMX_RH, -RMX_RH), make_float2(RMX_S1, -RMX_C1));      // ka = 1: W1 W2 W3
+    {                                                                              // ka = 2: W2 W4 W6
+        float2 &a0 = v[8], &a1 = v[9], &a2 = v[10], &a3 = v[11];
+        const float2 t0 = make_float2(a0.x + a2.y, a0.y - a2.x);                   // a0 + (-i) a2
+        const float2 t1 = make_float2(a0.x - a2.y, a0.y + a2.x);
+        const float2 A1 = make_float2((a1.x + a1.y) * RMX_RH, (a1.y - a1.x) * RMX_RH);
+        const float2 t2 = cfma(A1, a3, make_float2(-RMX_RH, -RMX_RH));
+        const float2 t3 = twice_minus(A1, t2);
+        dft4_tail(a0, a1, a2, a3, t0, t1, t2, t3);
+    }
+    dft4_tw<true>(v[12], v[13], v[14], v[15], make_float2(1.f, 0.f), make_float2(RMX_S1, -RMX_C1),
+                  make_float2(-RMX_RH, -RMX_RH), make_float2(-RMX_C1, RMX_S1));    // ka = 3: W3 W6 W9
+    // un-transpose (pure register renaming): X[ka + 4kb] sits in v[4ka + kb]
     float2 t;
     t = v[1];  v[1] = v[4];   v[4] = t;
     t = v[2];  v[2] = v[8];   v[8] = t;
@@ -82,6 +116,27 @@ __device__ __forceinline__ void dft16(float2 (&v)[16]) {
     t = v[6];  v[6] = v[9];   v[9] = t;
     t = v[7];  v[7] = v[13];  v[13] = t;
     t = v[11]; v[11] = v[14]; v[14] = t;
+}
+
+// 16-point DFT, X[k] = sum_q v[q] W16^(qk), natural order in, natural order out (150 instructions).
+__device__ __forceinline__ void dft16(float2 (&v)[16]) {
+    // q = 4*q1 + q0, k = ka + 4*kb.  Layer 1: DFT4 over q1 for each q0 -> y[q0][ka] in v[q0+4ka].
+    dft4(v[0], v[4], v[8], v[12]);
+    dft4(v[1], v[5], v[9], v[13]);
+    dft4(v[2], v[6], v[10], v[14]);
+    dft4(v[3], v[7], v[11], v[15]);
+    dft16_layer2(v);
+}
+
+// 16-point DFT of (v[q] * w[q]): the per-slot pre-twiddles (TW1, TW2, W32, or a whole spectrum for
+// the conj-multiply) are merged into layer 1.  W0_IS_ONE: w[0] == 1 (slot 0 of TW2 / W32).
+template <bool W0_IS_ONE>
+__device__ __forceinline__ void dft16_tw(float2 (&v)[16], const float2 (&w)[16]) {
+    dft4_tw<W0_IS_ONE>(v[0], v[4], v[8], v[12], w[0], w[4], w[8], w[12]);
+    dft4_tw<false>(v[1], v[5], v[9], v[13], w[1], w[5], w[9], w[13]);
+    dft4_tw<false>(v[2], v[6], v[10], v[14], w[2], w[6], w[10], w[14]);
+    dft4_tw<false>(v[3], v[7], v[11], v[15], w[3], w[7], w[11], w[15]);
+    dft16_layer2(v);
 }
 
 // W32^q, q = 0..15 (exp(-2*pi*i*q/32)): the per-slot part of the odd sub-transform's W_L^n.
@@ -189,6 +244,19 @@ __device__ __forceinline__ void mul_tw2(float2 (&v)[16], const float2* tw2_lds, 
 __device__ __forceinline__ void mul_tw1(float2 (&v)[16], const float2 (&tw1)[16]) {
 #pragma unroll
     for (int k = 0; k < 16; ++k) v[k] = cmul(v[k], tw1[k]);
+}
+
+// x[k] += s * x[k] of lane^1 for 8 registers, one v_fmac_f32_dpp each (quad_perm [1,0,3,2]).  hipcc
+// does not form this instruction from the mov_dpp builtin, and inside asm the VALU-write -> DPP-read
+// hazard (2 wait states) is ours: one s_nop 1 in front covers all eight (they do not feed each other).
+__device__ __forceinline__ void pair_fmac8(float& x0, float& x1, float& x2, float& x3, float& x4, float& x5,
+                                           float& x6, float& x7, float s) {
+#define RMX_DPPF(n) "v_fmac_f32_dpp %" #n ", %" #n ", %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+    asm volatile("s_nop 1\n\t" RMX_DPPF(0) RMX_DPPF(1) RMX_DPPF(2) RMX_DPPF(3) RMX_DPPF(4) RMX_DPPF(5) RMX_DPPF(6)
+                     RMX_DPPF(7)
+                 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7)
+                 : "v"(s));
+#undef RMX_DPPF
 }
 
 // lane <-> lane^1 exchange (DPP quad_perm [1,0,3,2]); folds into the consuming VOP2 as a DPP operand

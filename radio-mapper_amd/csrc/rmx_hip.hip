@@ -20,6 +20,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/rmx.h"
@@ -28,7 +29,7 @@
 namespace rmx {
 
 struct PairItem {
-    int i, j, out, pad;
+    int i, j, out, run;   // run: items left in this anchor run (same i), this one included
 };
 
 // LDS carve (bytes) of both kernels: exchange image, TW2 table, reduction words
@@ -345,7 +346,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_pair_res(
     const float4* __restrict__ spec, const float4* __restrict__ tw1_g, const float2* __restrict__ tw2_g,
     const PairItem* __restrict__ items, const int* __restrict__ part_begin, int n_parts, int n_buoys, int n_pairs,
     int xcd_map, long first_window, float out_scale, int* __restrict__ lag_int, float* __restrict__ lag_frac,
-    float* __restrict__ peak) {
+    float* __restrict__ peak, int dbg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2* xl = reinterpret_cast<float2*>(smem);
     float2* tw2_lds = reinterpret_cast<float2*>(smem + kLdsXchg);
@@ -403,7 +404,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_pair_res(
             v[2 * j] = make_float2(b.y * a.x - b.x * a.y, b.x * a.x + b.y * a.y);
             v[2 * j + 1] = make_float2(b.w * a.z - b.z * a.w, b.z * a.z + b.w * a.w);
         }
-        if (it + 1 < it_end) {   // request the next pair's spectra: a whole pair of compute hides it
+        if (it + 1 < it_end && !(dbg & 16)) {   // request the next pair's spectra: a whole pair of compute hides it
             pi = items[it + 1];
             const float4* xj = spec + (wbase + pi.j) * (8 * kThreads);
 #pragma unroll
@@ -417,16 +418,18 @@ __global__ __launch_bounds__(kThreads, 2) void k_pair_res(
         }
         dft16(v);                     // k2 -> n0   (role C)
         mul_tw2(v, tw2_lds, u & 15);  // W_256^(k1*n0)
+        if (!(dbg & 4)) {
         xchg_bc_write_c(xl, v, t);
         wave_lds_fence();
         xchg_bc_read_b(xl, v, t);
+        }
         dft16(v);                     // k1 -> n1   (role B)
-        xchg_b_write(xl, v, t);       // into this half wave's own region
-        __syncthreads();              // the pair's only barrier; also publishes pair it-1's winners
-        if (prev_out >= 0 && t == ((it - it_begin) & 7) * 64)
+        if (!(dbg & 8)) xchg_b_write(xl, v, t);       // into this half wave's own region
+        if (!(dbg & 1)) __syncthreads();              // the pair's only barrier; also publishes pair it-1's winners
+        if (!(dbg & 2) && prev_out >= 0 && t == ((it - it_begin) & 7) * 64)
             resolve_pair(reinterpret_cast<const float*>(magbuf + (buf ^ 1) * (4 * kThreads)), red + (buf ^ 1) * 8,
                          obase + prev_out, out_scale, lag_int, lag_frac, peak);
-        xchg_a_read(xl, v, t);
+        if (!(dbg & 8)) xchg_a_read(xl, v, t);
         mul_tw1(v, tw1);              // W_M^(u*k0) [* W_L^u on odd lanes]
         dft16(v);                     // k0 -> n2   (role A): e[n] (even lanes) / o[n]*W_L^u (odd lanes)
         if (p) {
@@ -441,6 +444,10 @@ __global__ __launch_bounds__(kThreads, 2) void k_pair_res(
             mag[q] = rx * rx + ry * ry;
         }
         if (p && u == 0) mag[0] = -1.0f;   // lag -M is not part of the 'full' output
+        if (dbg & 2) { float s = 0; 
+#pragma unroll
+            for (int q = 0; q < 16; ++q) s += mag[q];
+            if (s == 12345.678f) lag_int[0] = 1; prev_out = out_idx; continue; }
         float4* mb = magbuf + buf * (4 * kThreads) + t;
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4)
@@ -462,6 +469,289 @@ __global__ __launch_bounds__(kThreads, 2) void k_pair_res(
         const int buf = (it_end - 1 - it_begin) & 1;
         resolve_pair(reinterpret_cast<const float*>(magbuf + buf * (4 * kThreads)), red + buf * 8, obase + prev_out,
                      out_scale, lag_int, lag_frac, peak);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused window kernel: one workgroup (512 threads, <= 256 VGPRs, one per CU) per capture window.
+//   phase 1  forward spectra of all B buoys -> this window's scratch (thread-private layout: every
+//            thread later re-reads exactly the float4s it stored, so no visibility protocol is needed)
+//   phase 2  anchor runs over the pair list: X_i stays in registers for its run, X_j streams one pair
+//            ahead; conj-multiply merged into the first radix-16 pass; ONE workgroup barrier per pair.
+// LDS: two exchange images (alternating by transform/pair, which is what makes one barrier enough:
+// a wave only writes its own half-wave regions of the image the others are not reading), the TW2
+// table, and two small double-buffered records per wave for the argmax: the wave's winner with its
+// in-wave neighbour taps, and a "halo" of the |r|^2 of its lanes 0,1,62,63 for neighbours that sit
+// in another wave.  The pair's winner is resolved by one lane after the NEXT pair's barrier.
+constexpr int kLdsWinImg = kLdsXchg;                                 // 69632 each, two of them
+constexpr int kLdsWinTw2 = 2 * kLdsWinImg;
+constexpr int kLdsWinHalo = kLdsWinTw2 + kLdsTw2;                     // [2][8][4][16] float
+constexpr int kLdsWinRed = kLdsWinHalo + 2 * 8 * 4 * 16 * 4;          // [2][8] float4
+constexpr int kLdsWinBytes = kLdsWinRed + 2 * 8 * 16;
+
+__device__ __forceinline__ void k_to_owner(int kk, int& tt, int& q) {
+    const int par = (kk >= kM - 1) ? 0 : 1;
+    const int n = par ? (kk + 1) : (kk - (kM - 1));
+    tt = 2 * (n & 255) + par;
+    q = n >> 8;
+}
+
+// Executed by ONE whole wave after the barrier that published the records (wave-uniform call):
+// lanes 0..7 fetch the 8 wave records, two DPP reductions pick (max |r|^2, lowest 'full' index), the
+// neighbour taps come from the winner's record or from the halo rows; lane 0 stores the 12 bytes.
+__device__ __forceinline__ void resolve_win(int lane, const float4* red, const float* halo, long out_pos,
+                                            float out_scale, int* __restrict__ lag_int,
+                                            float* __restrict__ lag_frac, float* __restrict__ peak) {
+    float4 e = make_float4(-3.0f, __builtin_bit_cast(float, 0x7fffffff), -2.0f, -2.0f);
+    if (lane < 8) e = red[lane];
+    const float gmax = wave_max_f32(e.x);
+    const int k = __builtin_bit_cast(int, e.y);
+    const int kstar = wave_min_i32(e.x == gmax ? k : 0x7fffffff);
+    const unsigned long long win = __ballot(e.x == gmax && k == kstar);
+    const int wlane = __builtin_ctzll(win);
+    const float tm = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e.z), wlane));
+    const float tp = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e.w), wlane));
+    // halo rows (always read, clamped): only lanes 0,1,62,63 of a wave can own a cross-wave neighbour
+    auto halo_tap = [&](int kk) -> float {
+        kk = kk < 0 ? 0 : (kk > 2 * kM - 2 ? 2 * kM - 2 : kk);
+        int tt, q;
+        k_to_owner(kk, tt, q);
+        const int ln = tt & 63;
+        const int row = ln < 2 ? ln : (ln >= 62 ? ln - 60 : 0);
+        return halo[(((tt >> 6) * 4) + row) * 16 + q];
+    };
+    const float hm = halo_tap(kstar - 1), hp = halo_tap(kstar + 1);
+    const float b = sqrtf(gmax) * out_scale;
+    const float a = sqrtf(tm >= 0.0f ? tm : hm) * out_scale;
+    const float c = sqrtf(tp >= 0.0f ? tp : hp) * out_scale;
+    const double den = (double)a - 2.0 * (double)b + (double)c;
+    float frac = 0.0f;
+    if (kstar > 0 && kstar < 2 * kM - 2 && den != 0.0) frac = (float)(0.5 * ((double)a - (double)c) / den);
+    if (lane == 0) {
+        lag_int[out_pos] = kstar - (kM - 1);
+        lag_frac[out_pos] = frac;
+        peak[out_pos] = b;
+    }
+}
+
+template <bool U8>
+__global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq_v, float4* __restrict__ spec,
+                                                     const float4* __restrict__ tw1_g,
+                                                     const float2* __restrict__ tw2_g,
+                                                     const PairItem* __restrict__ items, int n_items, int n_buoys,
+                                                     int n_pairs, long first_window, float fwd_scale,
+                                                     float out_scale, int* __restrict__ lag_int,
+                                                     float* __restrict__ lag_frac, float* __restrict__ peak) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2* img0 = reinterpret_cast<float2*>(smem);
+    float2* img1 = reinterpret_cast<float2*>(smem + kLdsWinImg);
+    float2* tw2_lds = reinterpret_cast<float2*>(smem + kLdsWinTw2);
+    float* halo = reinterpret_cast<float*>(smem + kLdsWinHalo);
+    float4* red = reinterpret_cast<float4*>(smem + kLdsWinRed);
+
+    const int t = threadIdx.x;
+    const int p = t & 1, u = t >> 1;
+    const int lane = t & 63, wave = t >> 6;
+    const int wl = blockIdx.x;
+    const long wbase = (long)wl * n_buoys;
+
+    load_tw2_to_lds(tw2_lds, tw2_g, t);
+    float2 tw1[16];
+    load_tw1(tw1, tw1_g, t);
+    float2 w32r[16];   // odd lanes: W32^q (the per-slot part of W_L^n), even lanes: 1
+#pragma unroll
+    for (int q = 0; q < 16; ++q) w32r[q] = p ? w32(q) : make_float2(1.0f, 0.0f);
+    __syncthreads();
+
+    // ---------------- phase 1: forward spectra ----------------
+    {
+        float2 xin[16];
+        auto load_x = [&](int b) __attribute__((always_inline)) {
+            const long item = (first_window + wl) * (long)n_buoys + b;
+            if constexpr (U8) {
+                const uchar2* x = reinterpret_cast<const uchar2*>(iq_v) + item * kM;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const uchar2 bb = x[q * 256 + u];
+                    xin[q] = make_float2((float)bb.x - 127.5f, (float)bb.y - 127.5f);
+                }
+            } else {
+                const float2* x = reinterpret_cast<const float2*>(iq_v) + item * kM;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) xin[q] = x[q * 256 + u];
+            }
+        };
+        load_x(0);
+        for (int b = 0; b < n_buoys; ++b) {
+            float2 v[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v[q] = xin[q];
+            load_x(b + 1 < n_buoys ? b + 1 : b);   // next buoy's samples fly during this transform
+            float2* img = (b & 1) ? img1 : img0;
+            dft16_tw<true>(v, w32r);   // odd sub-transform input x*W32^q (W_L^u is folded into tw1)
+            mul_tw1(v, tw1);
+            xchg_a_write(img, v, t);
+            __syncthreads();
+            xchg_b_read(img, v, t);
+            dft16(v);
+            mul_tw2(v, tw2_lds, u & 15);
+            xchg_bc_write_b(img, v, t);
+            wave_lds_fence();
+            xchg_bc_read_c(img, v, t);
+            dft16(v);
+            float4* out = spec + (wbase + b) * (8 * kThreads);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                out[j * kThreads + t] = make_float4(v[2 * j].x * fwd_scale, v[2 * j].y * fwd_scale,
+                                                    v[2 * j + 1].x * fwd_scale, v[2 * j + 1].y * fwd_scale);
+        }
+    }
+    if (n_items <= 0) return;
+
+    // ---------------- phase 2: pairs ----------------
+    const float sgn = p ? -1.0f : 1.0f;
+    const int kbase = p ? (u - 1) : (u + kM - 1);
+    const long obase = (first_window + wl) * (long)n_pairs;
+    const int hl = lane < 2 ? lane : lane - 60;            // halo row of lanes 0,1,62,63
+    const bool is_halo = lane < 2 || lane >= 62;
+    float2 sa[16], sb[16];   // anchor X_i (multiplier) and streamed X_j, as 16 complex each
+
+    auto load_spec = [&](float2 (&d)[16], int b) __attribute__((always_inline)) {
+        const float4* x = spec + (wbase + b) * (8 * kThreads);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float4 w = x[j * kThreads + t];
+            d[2 * j] = make_float2(w.x, w.y);
+            d[2 * j + 1] = make_float2(w.z, w.w);
+        }
+    };
+
+    // Two pairs are in flight per loop trip (software pipeline, one workgroup barrier per trip):
+    //   pair B = it   : first half  (conj-multiply + DFT16, wave-local exchange, TW2 + DFT16, image write)
+    //   pair A = it-1 : second half (image read, TW1 + DFT16, W32, lane-pair butterfly, |.|^2, argmax)
+    // The two halves use different exchange images and are interleaved so that every LDS round trip
+    // of one pair is covered by ~200 independent VALU instructions of the other.
+    float2 va[16], vb[16];
+    const float4* tw2row = reinterpret_cast<const float4*>(tw2_lds + (u & 15) * kTw2RowF2);
+
+    // items are read one trip ahead with a scalar load at the very top of the trip, BEFORE any LDS
+    // access is issued (scalar loads share lgkmcnt with LDS: a wait for one drains the other).
+    PairItem cur = items[0];
+    PairItem nxt = items[n_items > 1 ? 1 : 0];
+    auto first_half_begin = [&]() __attribute__((always_inline)) {   // product + DFT16 (role C)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) vb[q] = make_float2(sb[q].y, sb[q].x);
+        dft16_tw<false>(vb, sa);
+        // keep the requests below the arithmetic that still reads sa/sb: the new values can then
+        // land in the same registers (no loop-carried copies), with a whole pair of latency cover.
+        // (Pure arithmetic is not ordered by sched_barrier at instruction selection: pin its results.)
+#pragma unroll
+        for (int q = 0; q < 16; q += 4)
+            asm volatile("" : "+v"(vb[q].x), "+v"(vb[q].y), "+v"(vb[q + 1].x), "+v"(vb[q + 1].y), "+v"(vb[q + 2].x),
+                         "+v"(vb[q + 2].y), "+v"(vb[q + 3].x), "+v"(vb[q + 3].y));
+        __builtin_amdgcn_sched_barrier(0);
+        load_spec(sb, nxt.j);
+        if (cur.run == 1) load_spec(sa, nxt.i);    // last pair of this anchor's run
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto first_half_end = [&](float2* img) __attribute__((always_inline)) {    // TW2 + DFT16 (role B), publish
+        float2 w2[16];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float4 w = tw2row[j];
+            w2[2 * j] = make_float2(w.x, w.y);
+            w2[2 * j + 1] = make_float2(w.z, w.w);
+        }
+        dft16_tw<true>(vb, w2);
+        xchg_b_write(img, vb, t);
+    };
+    float mag[16];
+    auto second_half_mid = [&]() __attribute__((always_inline)) {    // W32, lane-pair butterfly, |.|^2
+#pragma unroll
+        for (int q = 1; q < 16; ++q) va[q] = cmul(va[q], w32r[q]);
+        pair_fmac8(va[0].x, va[0].y, va[1].x, va[1].y, va[2].x, va[2].y, va[3].x, va[3].y, sgn);
+        pair_fmac8(va[4].x, va[4].y, va[5].x, va[5].y, va[6].x, va[6].y, va[7].x, va[7].y, sgn);
+        pair_fmac8(va[8].x, va[8].y, va[9].x, va[9].y, va[10].x, va[10].y, va[11].x, va[11].y, sgn);
+        pair_fmac8(va[12].x, va[12].y, va[13].x, va[13].y, va[14].x, va[14].y, va[15].x, va[15].y, sgn);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) mag[q] = fmaf(va[q].x, va[q].x, va[q].y * va[q].y);
+        if (p && u == 0) mag[0] = -1.0f;         // lag -M is not part of the 'full' output
+    };
+    auto second_half_end = [&](int buf) __attribute__((always_inline)) {    // wave argmax, taps, publish
+        if (is_halo) {
+            float4* hp = reinterpret_cast<float4*>(halo + ((buf * 8 + wave) * 4 + hl) * 16);
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4)
+                hp[q4] = make_float4(mag[4 * q4], mag[4 * q4 + 1], mag[4 * q4 + 2], mag[4 * q4 + 3]);
+        }
+        float tmax = mag[0];
+#pragma unroll
+        for (int q = 1; q < 16; ++q) tmax = fmaxf(tmax, mag[q]);
+        int qsel = 16;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) qsel = min(qsel, mag[q] == tmax ? q : 16);   // lowest slot holding the max
+        const int kq = kbase + qsel * 256;
+        const float wmax = wave_max_f32(tmax);
+        const int kw = wave_min_i32(tmax == wmax ? kq : 0x7fffffff);
+        // the winner's neighbours k*-1, k*+1 live in lanes l*-2, l*+2 (same slot) when those exist
+        int ts, qs;
+        k_to_owner(kw, ts, qs);
+        const int ls = ts & 63;
+        float sel = mag[0];
+#pragma unroll
+        for (int q = 1; q < 16; ++q) sel = (q == qs) ? mag[q] : sel;
+        const int seli = __builtin_bit_cast(int, sel);
+        const float tapm = ls >= 2 ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(seli, ls >= 2 ? ls - 2 : 0)) : -2.0f;
+        const float tapp = ls <= 61 ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(seli, ls <= 61 ? ls + 2 : 63)) : -2.0f;
+        if (lane == 0) red[buf * 8 + wave] = make_float4(wmax, __builtin_bit_cast(float, kw), tapm, tapp);
+    };
+
+    load_spec(sa, cur.i);
+    load_spec(sb, cur.j);
+    // prologue: first half of pair 0 (images/records alternate on the pair index)
+    first_half_begin();
+    xchg_bc_write_c(img0, vb, t);
+    wave_lds_fence();
+    xchg_bc_read_b(img0, vb, t);
+    first_half_end(img0);
+    __syncthreads();
+    int prev_out = cur.out;
+    for (int it = 1; it < n_items; ++it) {
+        cur = nxt;
+        nxt = items[it + 1 < n_items ? it + 1 : it];
+        {   // force the scalar load's wait here, ahead of the LDS traffic of this trip
+            int pin = nxt.i + nxt.j;
+            asm volatile("" : "+s"(pin));
+            (void)pin;
+        }
+        float2* imgA = (it & 1) ? img0 : img1;   // pair it-1
+        float2* imgB = (it & 1) ? img1 : img0;   // pair it
+        xchg_a_read(imgA, va, t);                // A: 16 LDS reads in flight ...
+        first_half_begin();                      // B: ... under ~200 VALU + the next pair's global loads
+        xchg_bc_write_c(imgB, vb, t);            // B: wave-local exchange, writes ...
+        dft16_tw<false>(va, tw1);                // A: ... under TW1 + DFT16 (k0 -> n2)
+        wave_lds_fence();
+        xchg_bc_read_b(imgB, vb, t);             // B: ... reads ...
+        second_half_mid();                       // A: ... under W32 / butterfly / |.|^2
+        first_half_end(imgB);                    // B: TW2 + DFT16, image write ...
+        second_half_end((it - 1) & 1);           // A: ... under the argmax
+        __syncthreads();
+        if (wave == (it & 7))
+            resolve_win(lane, red + ((it - 1) & 1) * 8, halo + ((it - 1) & 1) * (8 * 4 * 16), obase + prev_out,
+                        out_scale, lag_int, lag_frac, peak);
+        prev_out = cur.out;
+    }
+    {   // epilogue: second half of the last pair
+        const int last = n_items - 1;
+        float2* imgA = (last & 1) ? img1 : img0;
+        xchg_a_read(imgA, va, t);
+        dft16_tw<false>(va, tw1);
+        second_half_mid();
+        second_half_end(last & 1);
+        __syncthreads();
+        if (wave == 0)
+            resolve_win(lane, red + (last & 1) * 8, halo + (last & 1) * (8 * 4 * 16), obase + prev_out, out_scale,
+                        lag_int, lag_frac, peak);
     }
 }
 
@@ -491,7 +781,9 @@ struct rmx_ctx {
     int chunk_windows = 0;
     int pairs_per_block = 7;
     bool timing = false;
-    bool resident = true;   // pair kernel variant: 1 workgroup/CU with resident tables
+    int dbg = 0;
+    bool resident = true;
+    bool fused = true;      // one kernel per chunk: forward spectra + pairs in one workgroup per window   // pair kernel variant: 1 workgroup/CU with resident tables
     // device buffers
     float4* d_spec = nullptr;
     float4* d_tw1 = nullptr;
@@ -586,7 +878,9 @@ static int build_plan(rmx_ctx* c, const int32_t* pairs, int n_pairs) {
             return fail(c, RMX_E_INVAL, "pair %d = (%d,%d) out of range for %d buoys", q, i, j, c->n_buoys);
     }
     std::vector<PairItem> items(n_pairs);
-    for (int q = 0; q < n_pairs; ++q) items[q] = PairItem{pl[2 * q], pl[2 * q + 1], q, 0};
+    for (int q = 0; q < n_pairs; ++q) items[q] = PairItem{pl[2 * q], pl[2 * q + 1], q, 1};
+    for (int q = n_pairs - 2; q >= 0; --q)
+        if (items[q].i == items[q + 1].i) items[q].run = items[q + 1].run + 1;
     const int ppb = c->pairs_per_block > 0 ? c->pairs_per_block : 7;
     const int n_parts = (n_pairs + ppb - 1) / ppb;
     std::vector<int> pb(n_parts + 1);
@@ -672,6 +966,8 @@ int rmx_create(rmx_ctx** out, int device_id, int n_buoys, int n_samples, int max
         RMX_HIP(c, hipFuncSetAttribute((const void*)k_fwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
         RMX_HIP(c, hipFuncSetAttribute((const void*)k_fwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
         RMX_HIP(c, hipFuncSetAttribute((const void*)k_pair_res, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsResBytes));
+        RMX_HIP(c, hipFuncSetAttribute((const void*)k_win<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsWinBytes));
+        RMX_HIP(c, hipFuncSetAttribute((const void*)k_win<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsWinBytes));
         RMX_HIP(c, hipFuncSetAttribute((const void*)k_pair_str, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
         return RMX_OK;
     };
@@ -732,6 +1028,14 @@ int rmx_set_option(rmx_ctx* c, const char* key, long value) {
     if (!strcmp(key, "pairs_per_block")) {
         if (value < 1 || value > 1 << 20) return fail(c, RMX_E_INVAL, "pairs_per_block %ld out of range", value);
         c->pairs_per_block = (int)value;
+        return RMX_OK;
+    }
+    if (!strcmp(key, "dbg")) {
+        c->dbg = (int)value;
+        return RMX_OK;
+    }
+    if (!strcmp(key, "fused")) {
+        c->fused = value != 0;
         return RMX_OK;
     }
     if (!strcmp(key, "resident")) {
@@ -813,6 +1117,24 @@ int rmx_xcorr_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pa
     }
     for (int w0 = 0; w0 < n_windows; w0 += c->chunk_windows) {
         const int wc = (n_windows - w0 < c->chunk_windows) ? n_windows - w0 : c->chunk_windows;
+        if (c->fused) {
+            if (c->timing) RMX_HIP(c, hipEventRecord(c->ev[c->ev_used], c->stream));
+            if (u8)
+                hipLaunchKernelGGL(k_win<true>, dim3(wc), dim3(kThreads), kLdsWinBytes, c->stream, d_iq, c->d_spec,
+                                   c->d_tw1, c->d_tw2, c->d_items, n_pairs, c->n_buoys, n_pairs, (long)w0, fwd_scale,
+                                   out_scale, d_lag, d_frac, d_peak);
+            else
+                hipLaunchKernelGGL(k_win<false>, dim3(wc), dim3(kThreads), kLdsWinBytes, c->stream, d_iq, c->d_spec,
+                                   c->d_tw1, c->d_tw2, c->d_items, n_pairs, c->n_buoys, n_pairs, (long)w0, fwd_scale,
+                                   out_scale, d_lag, d_frac, d_peak);
+            RMX_HIP(c, hipGetLastError());
+            if (c->timing) {
+                RMX_HIP(c, hipEventRecord(c->ev[c->ev_used + 1], c->stream));
+                c->ev_used += 2;
+                c->ev_kind.push_back(1);
+            }
+            continue;
+        }
         const long first_item = (long)w0 * c->n_buoys;
         const int n_items = wc * c->n_buoys;
         if (c->timing) RMX_HIP(c, hipEventRecord(c->ev[c->ev_used], c->stream));
@@ -833,7 +1155,7 @@ int rmx_xcorr_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pa
         if (c->resident)
             hipLaunchKernelGGL(k_pair_res, dim3(wc * n_parts), dim3(kThreads), kLdsResBytes, c->stream, c->d_spec,
                                c->d_tw1, c->d_tw2, c->d_items, c->d_part_begin, n_parts, c->n_buoys, n_pairs,
-                               xcd_map, (long)w0, out_scale, d_lag, d_frac, d_peak);
+                               xcd_map, (long)w0, out_scale, d_lag, d_frac, d_peak, c->dbg);
         else
             hipLaunchKernelGGL(k_pair_str, dim3(wc * n_parts), dim3(kThreads), kLdsBytes, c->stream, c->d_spec,
                                c->d_tw1, c->d_tw2, c->d_items, c->d_part_begin, n_parts, c->n_buoys, n_pairs,

@@ -28,7 +28,7 @@ def parity():
     eng.close()
     return ok
 
-def timing(W=4096, B=8, N=4096, chunk=None, ppb=None, reps=5, resident=1):
+def timing(W=4096, B=8, N=4096, chunk=None, ppb=None, reps=5, resident=1, dbg=0, fused=1):
     dev = torch.device("cuda:0")
     gen = torch.Generator(device=dev); gen.manual_seed(1)
     x = torch.randn((W, B, N, 2), device=dev, generator=gen, dtype=torch.float32) * 30.0
@@ -42,6 +42,8 @@ def timing(W=4096, B=8, N=4096, chunk=None, ppb=None, reps=5, resident=1):
     if ppb: eng.set_option("pairs_per_block", ppb)
     eng.set_option("timing", 1)
     eng.set_option("resident", resident)
+    eng.set_option("dbg", dbg)
+    eng.set_option("fused", fused)
     for _ in range(2):
         eng.correlate_device(x.data_ptr(), W, lag.data_ptr(), frac.data_ptr(), peak.data_ptr())
     torch.cuda.synchronize()
@@ -55,7 +57,7 @@ def timing(W=4096, B=8, N=4096, chunk=None, ppb=None, reps=5, resident=1):
     tm = eng.last_timing()
     t = min(ts)
     alg = W * P * (16 * N + 12)
-    print(f"W={W} B={B} res={resident} chunk={chunk} ppb={ppb}: best {t:.3f} ms  med {sorted(ts)[len(ts)//2]:.3f}  "
+    print(f"fused={fused} dbg={dbg} W={W} B={B} res={resident} chunk={chunk} ppb={ppb}: best {t:.3f} ms  med {sorted(ts)[len(ts)//2]:.3f}  "
           f"fwd {tm['fwd_ms']:.3f} ms/{tm['fwd_launches']}  pair {tm['pair_ms']:.3f} ms/{tm['pair_launches']}  "
           f"=> {W*P*N/t/1e6:.1f} Gsamp/s  roofline {alg/t/1e-3/8e12*100:.1f}% of 8 TB/s")
     eng.close()
@@ -63,8 +65,5 @@ def timing(W=4096, B=8, N=4096, chunk=None, ppb=None, reps=5, resident=1):
 if __name__ == "__main__":
     print("lib:", xcorr.library_path(), "devices:", xcorr.device_count())
     parity()
-    for res in (1,):
-        for ppb in (7, 4, 14):
-            for chunk in (512, 4096):
-                timing(chunk=chunk, ppb=ppb, resident=res)
-    timing(chunk=4096, ppb=7, resident=0)
+    for chunk in (512, 4096):
+        timing(chunk=chunk, fused=1)
