@@ -216,7 +216,7 @@ def main():
                                    "(L=8192), 4096 windows per GPU resident in HBM",
                        "n_buoys": B, "n_pairs": P, "n_samples": N, "windows_per_gpu": W,
                        "windows_total": W_total, "parallelism": f"windows sharded x{n_gpus}, no collective"},
-            "roofline": {"bound": "hbm", "kernel": "k_pair", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "k_win (fused forward + pair kernel)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "alg_bytes_per_launch": alg_bytes_per_launch,
                          "launch_ms": pair_launch_ms,

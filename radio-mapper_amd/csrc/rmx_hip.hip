@@ -542,6 +542,10 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
                                                      int n_pairs, long first_window, float fwd_scale,
                                                      float out_scale, int* __restrict__ lag_int,
                                                      float* __restrict__ lag_frac, float* __restrict__ peak) {
+#ifndef RMX_ABLATE
+#define RMX_ABLATE 0
+#endif
+    constexpr int AB = RMX_ABLATE;   // timing-only ablation builds (wrong results), tools/ablate.sh
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2* img0 = reinterpret_cast<float2*>(smem);
     float2* img1 = reinterpret_cast<float2*>(smem + kLdsWinImg);
@@ -602,7 +606,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
             float4* out = spec + (wbase + b) * (8 * kThreads);
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                out[j * kThreads + t] = make_float4(v[2 * j].x * fwd_scale, v[2 * j].y * fwd_scale,
+                if (!(AB & 32)) out[j * kThreads + t] = make_float4(v[2 * j].x * fwd_scale, v[2 * j].y * fwd_scale,
                                                     v[2 * j + 1].x * fwd_scale, v[2 * j + 1].y * fwd_scale);
         }
     }
@@ -650,8 +654,10 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
             asm volatile("" : "+v"(vb[q].x), "+v"(vb[q].y), "+v"(vb[q + 1].x), "+v"(vb[q + 1].y), "+v"(vb[q + 2].x),
                          "+v"(vb[q + 2].y), "+v"(vb[q + 3].x), "+v"(vb[q + 3].y));
         __builtin_amdgcn_sched_barrier(0);
+        if (!(AB & 16)) {
         load_spec(sb, nxt.j);
         if (cur.run == 1) load_spec(sa, nxt.i);    // last pair of this anchor's run
+        }
         __builtin_amdgcn_sched_barrier(0);
     };
     auto first_half_end = [&](float2* img) __attribute__((always_inline)) {    // TW2 + DFT16 (role B), publish
@@ -663,7 +669,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
             w2[2 * j + 1] = make_float2(w.z, w.w);
         }
         dft16_tw<true>(vb, w2);
-        xchg_b_write(img, vb, t);
+        if (!(AB & 8)) xchg_b_write(img, vb, t);
     };
     float mag[16];
     auto second_half_mid = [&]() __attribute__((always_inline)) {    // W32, lane-pair butterfly, |.|^2
@@ -726,17 +732,23 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
         }
         float2* imgA = (it & 1) ? img0 : img1;   // pair it-1
         float2* imgB = (it & 1) ? img1 : img0;   // pair it
-        xchg_a_read(imgA, va, t);                // A: 16 LDS reads in flight ...
+        if (!(AB & 8)) xchg_a_read(imgA, va, t);                // A: 16 LDS reads in flight ...
         first_half_begin();                      // B: ... under ~200 VALU + the next pair's global loads
-        xchg_bc_write_c(imgB, vb, t);            // B: wave-local exchange, writes ...
+        if (!(AB & 4)) xchg_bc_write_c(imgB, vb, t);            // B: wave-local exchange, writes ...
         dft16_tw<false>(va, tw1);                // A: ... under TW1 + DFT16 (k0 -> n2)
+        if (!(AB & 4)) {
         wave_lds_fence();
         xchg_bc_read_b(imgB, vb, t);             // B: ... reads ...
+        }
         second_half_mid();                       // A: ... under W32 / butterfly / |.|^2
         first_half_end(imgB);                    // B: TW2 + DFT16, image write ...
-        second_half_end((it - 1) & 1);           // A: ... under the argmax
-        __syncthreads();
-        if (wave == (it & 7))
+        if (!(AB & 2)) second_half_end((it - 1) & 1);           // A: ... under the argmax
+        else { float s = 0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) s += mag[q];
+            if (s == 12345.678f) lag_int[0] = 1; }
+        if (!(AB & 1)) __syncthreads();
+        if (!(AB & 2) && wave == (it & 7))
             resolve_win(lane, red + ((it - 1) & 1) * 8, halo + ((it - 1) & 1) * (8 * 4 * 16), obase + prev_out,
                         out_scale, lag_int, lag_frac, peak);
         prev_out = cur.out;
@@ -948,10 +960,15 @@ int rmx_create(rmx_ctx** out, int device_id, int n_buoys, int n_samples, int max
         RMX_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         c->own_stream = true;
         const char* env = getenv("RMX_CHUNK_WINDOWS");
-        int chunk = env ? atoi(env) : 512;
+        int chunk = env ? atoi(env) : 4096;
         if (chunk < 8) chunk = 8;
         chunk = (chunk + 7) & ~7;
         if (chunk > max_windows) chunk = max_windows;
+        {   // spectra scratch = chunk * B * 64 KiB: keep it under 8 GiB
+            const long per_win = (long)n_buoys * (8 * kThreads) * (long)sizeof(float4);
+            const long cap = (8L << 30) / per_win;
+            if (chunk > cap) chunk = (int)(cap > 8 ? (cap & ~7L) : 8);
+        }
         c->chunk_windows = chunk;
         c->spec_bytes = (size_t)chunk * n_buoys * (8 * kThreads) * sizeof(float4);
         RMX_HIP(c, hipMalloc((void**)&c->d_spec, c->spec_bytes));

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Condense a tools/profile.sh output directory into profiles/<tag>_*.{csv,json}.
+
+  python tools/summarize_prof.py gpurun_out/prof_<tag> <tag>
+
+Writes  profiles/<tag>_kernel_stats.csv   (rocprofv3 --kernel-trace --stats, our kernels only)
+        profiles/<tag>_pmc.json           (per-kernel averages of every collected counter)
+        profiles/traffic_latest.json      (HBM bytes per launch of the dominant kernel, for bench.py)
+HBM bytes follow MI355X_MICROARCH.md section HBM: FETCH_SIZE and WRITE_SIZE are in KiB and come
+from separate --pmc passes; on gfx950 FETCH_SIZE counts 64 B per 128-B request of a wide coalesced
+stream, so it is doubled; WRITE_SIZE is exact for 16-B-per-lane stores.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def main():
+    src, tag = sys.argv[1], sys.argv[2]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = os.path.join(root, "profiles")
+    os.makedirs(out, exist_ok=True)
+    ours = ("k_win", "k_fwd", "k_pair")
+    st = glob.glob(os.path.join(src, "stats", "*kernel_stats.csv"))
+    if st:
+        rows = list(csv.reader(open(st[0])))
+        keep = [rows[0]] + [r for r in rows[1:] if any(k in r[0] for k in ours)]
+        with open(os.path.join(out, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
+            csv.writer(f).writerows(keep)
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for p in glob.glob(os.path.join(src, "pmc_*", "*counter_collection.csv")):
+        for r in csv.DictReader(open(p)):
+            name = r["Kernel_Name"].split("(")[0].split("<")[0]
+            if any(k in name for k in ours):
+                agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    pmc = {k: {c: sum(v) / len(v) for c, v in d.items()} | {"launches_sampled": len(next(iter(d.values())))}
+           for k, d in agg.items()}
+    json.dump(pmc, open(os.path.join(out, f"{tag}_pmc.json"), "w"), indent=1, sort_keys=True)
+    dom = max(pmc, key=lambda k: pmc[k].get("SQ_WAVE_CYCLES", 0)) if pmc else None
+    if dom and "FETCH_SIZE" in pmc[dom] and "WRITE_SIZE" in pmc[dom]:
+        fetch, write = pmc[dom]["FETCH_SIZE"], pmc[dom]["WRITE_SIZE"]
+        traffic = {"kernel": dom, "hbm_bytes_per_launch": (2.0 * fetch + write) * 1024.0,
+                   "fetch_size_kib_raw": fetch, "write_size_kib": write,
+                   "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 64 B per 128-B request)",
+                   "tag": tag}
+        json.dump(traffic, open(os.path.join(out, "traffic_latest.json"), "w"), indent=1)
+        print(traffic)
+    print("kernels:", list(pmc))
+
+
+if __name__ == "__main__":
+    main()
