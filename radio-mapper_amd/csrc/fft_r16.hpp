@@ -92,6 +92,13 @@ __device__ __forceinline__ void dft4_tw(float2& a0, float2& a1, float2& a2, floa
     dft4_tail(a0, a1, a2, a3, t0, t1, t2, t3);
 }
 
+// component-wise swap (a struct copy of float2 can keep the array element in scratch memory)
+__device__ __forceinline__ void swap2(float2& a, float2& b) {
+    const float ax = a.x, ay = a.y;
+    a.x = b.x; a.y = b.y;
+    b.x = ax; b.y = ay;
+}
+
 // second radix-4 layer of the 16-point DFT with its constant inner twiddles W16^(q0*ka) merged
 __device__ __forceinline__ void dft16_layer2(float2 (&v)[16]) {
     dft4(v[0], v[1], v[2], v[3]);                                                  // ka = 0
@@ -109,13 +116,12 @@ __device__ __forceinline__ void dft16_layer2(float2 (&v)[16]) {
     dft4_tw<true>(v[12], v[13], v[14], v[15], make_float2(1.f, 0.f), make_float2(RMX_S1, -RMX_C1),
                   make_float2(-RMX_RH, -RMX_RH), make_float2(-RMX_C1, RMX_S1));    // ka = 3: W3 W6 W9
     // un-transpose (pure register renaming): X[ka + 4kb] sits in v[4ka + kb]
-    float2 t;
-    t = v[1];  v[1] = v[4];   v[4] = t;
-    t = v[2];  v[2] = v[8];   v[8] = t;
-    t = v[3];  v[3] = v[12];  v[12] = t;
-    t = v[6];  v[6] = v[9];   v[9] = t;
-    t = v[7];  v[7] = v[13];  v[13] = t;
-    t = v[11]; v[11] = v[14]; v[14] = t;
+    swap2(v[1], v[4]);
+    swap2(v[2], v[8]);
+    swap2(v[3], v[12]);
+    swap2(v[6], v[9]);
+    swap2(v[7], v[13]);
+    swap2(v[11], v[14]);
 }
 
 // 16-point DFT, X[k] = sum_q v[q] W16^(qk), natural order in, natural order out (150 instructions).
@@ -137,6 +143,49 @@ __device__ __forceinline__ void dft16_tw(float2 (&v)[16], const float2 (&w)[16])
     dft4_tw<false>(v[2], v[6], v[10], v[14], w[2], w[6], w[10], w[14]);
     dft4_tw<false>(v[3], v[7], v[11], v[15], w[3], w[7], w[11], w[15]);
     dft16_layer2(v);
+}
+
+// 16 complex values as two scalar arrays.  Long-lived register arrays (anchor / stream spectra) use
+// this instead of float2[16]: hipcc's SROA leaves the tail of a float2 array in scratch memory as
+// soon as one access is a struct copy or a vector-typed view, and every scratch access in the pair
+// loop costs a vmcnt(0) that drains the spectra requested a pair ahead.
+struct C16 {
+    float re[16], im[16];
+    __device__ __forceinline__ float2 get(int q) const { return make_float2(re[q], im[q]); }
+    __device__ __forceinline__ void set(int q, float x, float y) { re[q] = x; im[q] = y; }
+};
+template <bool W0_IS_ONE>
+__device__ __forceinline__ void dft16_tw(float2 (&v)[16], const C16& w) {
+    dft4_tw<W0_IS_ONE>(v[0], v[4], v[8], v[12], w.get(0), w.get(4), w.get(8), w.get(12));
+    dft4_tw<false>(v[1], v[5], v[9], v[13], w.get(1), w.get(5), w.get(9), w.get(13));
+    dft4_tw<false>(v[2], v[6], v[10], v[14], w.get(2), w.get(6), w.get(10), w.get(14));
+    dft4_tw<false>(v[3], v[7], v[11], v[15], w.get(3), w.get(7), w.get(11), w.get(15));
+    dft16_layer2(v);
+}
+
+// 16-point DFT of (v[q] * tw[q]) with the twiddle row fetched just in time from LDS: `row` holds the
+// 16 twiddles in layer-1 group order, row[2*q0 + h] = (tw[q0 + 8h], tw[q0 + 4 + 8h]) as float4, so
+// each DFT4 group needs two ds_read_b128 and only ~8 twiddle registers are live at a time.
+// tw[0] must be 1 (TW2 rows).
+__device__ __forceinline__ void dft16_tw_row(float2 (&v)[16], const float4* row) {
+#pragma unroll
+    for (int q0 = 0; q0 < 4; ++q0) {
+        const float4 f0 = row[2 * q0], f1 = row[2 * q0 + 1];
+        const float2 w0 = make_float2(f0.x, f0.y), w1 = make_float2(f0.z, f0.w);
+        const float2 w2 = make_float2(f1.x, f1.y), w3 = make_float2(f1.z, f1.w);
+        if (q0 == 0) dft4_tw<true>(v[0], v[4], v[8], v[12], w0, w1, w2, w3);
+        else dft4_tw<false>(v[q0], v[q0 + 4], v[q0 + 8], v[q0 + 12], w0, w1, w2, w3);
+    }
+    dft16_layer2(v);
+}
+
+// (x + iy) *= (wr + i wi) in place, 4 VALU instructions and one temporary, no result copies: used
+// under the odd-lane branch for the W32^q factors (the compiler's version copies every result back).
+__device__ __forceinline__ void cmul_inplace(float& x, float& y, float wr, float wi) {
+    float tmp;
+    asm volatile("v_mul_f32 %2, %0, %4\n\tv_mul_f32 %0, %0, %3\n\tv_fma_f32 %0, -%1, %4, %0\n\tv_fma_f32 %1, %1, %3, %2"
+                 : "+v"(x), "+v"(y), "=&v"(tmp)
+                 : "s"(wr), "s"(wi));
 }
 
 // W32^q, q = 0..15 (exp(-2*pi*i*q/32)): the per-slot part of the odd sub-transform's W_L^n.
@@ -179,7 +228,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 
 __device__ __forceinline__ void xchg_a_write(float2* lds, const float2 (&v)[16], int t) {
 #pragma unroll
-    for (int k0 = 0; k0 < 16; ++k0) lds[k0 * kBcHalf + t] = v[k0];
+    for (int k0 = 0; k0 < 16; ++k0) lds[k0 * kBcHalf + t] = make_float2(v[k0].x, v[k0].y);
 }
 __device__ __forceinline__ void xchg_a_read(const float2* lds, float2 (&v)[16], int t) {
 #pragma unroll
@@ -190,7 +239,7 @@ __device__ __forceinline__ void xchg_b_write(float2* lds, const float2 (&v)[16],
     const int p = t & 1, u = t >> 1, k0 = u >> 4, n0 = u & 15;
     float2* base = lds + k0 * kBcHalf + n0 * 2 + p;
 #pragma unroll
-    for (int n1 = 0; n1 < 16; ++n1) base[n1 * 32] = v[n1];
+    for (int n1 = 0; n1 < 16; ++n1) base[n1 * 32] = make_float2(v[n1].x, v[n1].y);
 }
 __device__ __forceinline__ void xchg_b_read(const float2* lds, float2 (&v)[16], int t) {
     const int p = t & 1, u = t >> 1, k0 = u >> 4, n0 = u & 15;
@@ -207,7 +256,7 @@ __device__ __forceinline__ void xchg_bc_write_b(float2* lds, const float2 (&v)[1
     const int p = t & 1, u = t >> 1, k0 = u >> 4, a = u & 15;
     float2* base = lds + k0 * kBcHalf + 2 * a + p;
 #pragma unroll
-    for (int k1 = 0; k1 < 16; ++k1) base[k1 * kBcRow] = v[k1];
+    for (int k1 = 0; k1 < 16; ++k1) base[k1 * kBcRow] = make_float2(v[k1].x, v[k1].y);
 }
 __device__ __forceinline__ void xchg_bc_read_c(const float2* lds, float2 (&v)[16], int t) {
     const int p = t & 1, u = t >> 1, k0 = u >> 4, a = u & 15;
@@ -219,7 +268,7 @@ __device__ __forceinline__ void xchg_bc_write_c(float2* lds, const float2 (&v)[1
     const int p = t & 1, u = t >> 1, k0 = u >> 4, a = u & 15;
     float2* base = lds + k0 * kBcHalf + a * kBcRow + p;
 #pragma unroll
-    for (int n0 = 0; n0 < 16; ++n0) base[2 * n0] = v[n0];
+    for (int n0 = 0; n0 < 16; ++n0) base[2 * n0] = make_float2(v[n0].x, v[n0].y);
 }
 __device__ __forceinline__ void xchg_bc_read_b(const float2* lds, float2 (&v)[16], int t) {
     const int p = t & 1, u = t >> 1, k0 = u >> 4, a = u & 15;

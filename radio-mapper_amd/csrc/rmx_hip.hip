@@ -28,6 +28,13 @@
 
 namespace rmx {
 
+using u32x4 = unsigned int __attribute__((ext_vector_type(4)));
+using u32x2 = unsigned int __attribute__((ext_vector_type(2)));
+using f32x4 = float __attribute__((ext_vector_type(4)));
+using f32x2 = float __attribute__((ext_vector_type(2)));
+// NOTE: __builtin_bit_cast(float, vec.y) on a vector ELEMENT is mis-lowered by this hipcc (every
+// element reads lane 0 of the vector); always bit_cast the whole vector, then take elements.
+
 struct PairItem {
     int i, j, out, run;   // run: items left in this anchor run (same i), this one included
 };
@@ -41,6 +48,14 @@ constexpr int kLdsBytes = kLdsXchg + kLdsTw2 + kLdsRed;
 __device__ __forceinline__ void load_tw2_to_lds(float2* tw2_lds, const float2* __restrict__ tw2_g, int t) {
     // tw2_g: [16][16] complex; LDS rows padded to kTw2RowF2
     if (t < 256) tw2_lds[(t >> 4) * kTw2RowF2 + (t & 15)] = tw2_g[t];
+}
+
+// same table in layer-1 group order for dft16_tw_row: stored[4*q0 + m] = tw2[a][q0 + 4*m]
+__device__ __forceinline__ void load_tw2_to_lds_grouped(float2* tw2_lds, const float2* __restrict__ tw2_g, int t) {
+    if (t < 256) {
+        const int a = t >> 4, q = t & 15;
+        tw2_lds[a * kTw2RowF2 + 4 * (q & 3) + (q >> 2)] = tw2_g[t];
+    }
 }
 
 __device__ __forceinline__ void load_tw1(float2 (&tw1)[16], const float4* __restrict__ tw1_g, int t) {
@@ -321,7 +336,8 @@ __device__ __forceinline__ void resolve_pair(const float* magbuf, const float2* 
     for (int w = 0; w < 8; ++w) {
         const float2 e = red[w];
         const float m = e.x;
-        const int k = __builtin_bit_cast(int, e.y);
+        const float ey = e.y;
+        const int k = __builtin_bit_cast(int, ey);
         if (m > gmax || (m == gmax && k < kstar)) { gmax = m; kstar = k; }
     }
     auto tap = [&](int kk) -> float {
@@ -502,15 +518,21 @@ __device__ __forceinline__ void k_to_owner(int kk, int& tt, int& q) {
 __device__ __forceinline__ void resolve_win(int lane, const float4* red, const float* halo, long out_pos,
                                             float out_scale, int* __restrict__ lag_int,
                                             float* __restrict__ lag_frac, float* __restrict__ peak) {
-    float4 e = make_float4(-3.0f, __builtin_bit_cast(float, 0x7fffffff), -2.0f, -2.0f);
-    if (lane < 8) e = red[lane];
-    const float gmax = wave_max_f32(e.x);
-    const int k = __builtin_bit_cast(int, e.y);
-    const int kstar = wave_min_i32(e.x == gmax ? k : 0x7fffffff);
-    const unsigned long long win = __ballot(e.x == gmax && k == kstar);
+    // record w = {max |r|^2, its lowest 'full' index (int bits), tap k*-1, tap k*+1}; scalar LDS reads
+    // (a float4 struct read back as int would live in scratch, and every scratch access costs a
+    // vmcnt wait that drains the spectra requested a pair ahead)
+    const float* rf = reinterpret_cast<const float*>(red) + 4 * (lane & 7);
+    const int* ri = reinterpret_cast<const int*>(rf);
+    const bool act = lane < 8;
+    const float ex = act ? rf[0] : -3.0f;
+    const int k = act ? ri[1] : 0x7fffffff;
+    const float ez = act ? rf[2] : -2.0f, ew = act ? rf[3] : -2.0f;
+    const float gmax = wave_max_f32(ex);
+    const int kstar = wave_min_i32(ex == gmax ? k : 0x7fffffff);
+    const unsigned long long win = __ballot(ex == gmax && k == kstar);
     const int wlane = __builtin_ctzll(win);
-    const float tm = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e.z), wlane));
-    const float tp = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e.w), wlane));
+    const float tm = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ez), wlane));
+    const float tp = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ew), wlane));
     // halo rows (always read, clamped): only lanes 0,1,62,63 of a wave can own a cross-wave neighbour
     auto halo_tap = [&](int kk) -> float {
         kk = kk < 0 ? 0 : (kk > 2 * kM - 2 ? 2 * kM - 2 : kk);
@@ -534,18 +556,27 @@ __device__ __forceinline__ void resolve_win(int lane, const float4* red, const f
     }
 }
 
+// Schedule of one window (all pairs i<j of B buoys; the anchor spectrum X_i is resident in registers,
+// X_j streams one pair ahead):
+//   anchor 0      X_0 is transformed straight into the anchor registers (never stored); every further
+//                 X_e is transformed once, stored once, and used at once, from registers, for (0,e);
+//   anchor i>=1   one anchor load, then the X_j stream, walking j down for odd i and up for even i so
+//                 that each anchor starts on the spectra the previous one touched last.
+// HBM/L2 traffic per window at B = 8: 8 inputs (256 KiB) + 7 spectrum stores (448 KiB) + 27
+// spectrum loads of 64 KiB, of which ~8 are L2-hot, instead of 8 stores + 35 loads.
 template <bool U8>
 __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq_v, float4* __restrict__ spec,
                                                      const float4* __restrict__ tw1_g,
-                                                     const float2* __restrict__ tw2_g,
-                                                     const PairItem* __restrict__ items, int n_items, int n_buoys,
-                                                     int n_pairs, long first_window, float fwd_scale,
-                                                     float out_scale, int* __restrict__ lag_int,
-                                                     float* __restrict__ lag_frac, float* __restrict__ peak) {
-#ifndef RMX_ABLATE
-#define RMX_ABLATE 0
+                                                     const float2* __restrict__ tw2_g, int n_buoys,
+                                                     long first_window, float fwd_scale, float out_scale,
+                                                     int* __restrict__ lag_int, float* __restrict__ lag_frac,
+                                                     float* __restrict__ peak, int dbg_rt) {
+#ifdef RMX_ABLATE
+    const int dbg = dbg_rt;   // timing-only ablation build (wrong results): tools/gpu_probe.py
+#else
+    constexpr int dbg = 0;
+    (void)dbg_rt;
 #endif
-    constexpr int AB = RMX_ABLATE;   // timing-only ablation builds (wrong results), tools/ablate.sh
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2* img0 = reinterpret_cast<float2*>(smem);
     float2* img1 = reinterpret_cast<float2*>(smem + kLdsWinImg);
@@ -557,135 +588,174 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
     const int p = t & 1, u = t >> 1;
     const int lane = t & 63, wave = t >> 6;
     const int wl = blockIdx.x;
-    const long wbase = (long)wl * n_buoys;
+    const int B = n_buoys;
+    const long wbase = (long)wl * B;
+    const int n_pairs = B * (B - 1) / 2;
+    const long obase = (first_window + wl) * (long)n_pairs;
 
-    load_tw2_to_lds(tw2_lds, tw2_g, t);
+    load_tw2_to_lds_grouped(tw2_lds, tw2_g, t);
     float2 tw1[16];
     load_tw1(tw1, tw1_g, t);
-    float2 w32r[16];   // odd lanes: W32^q (the per-slot part of W_L^n), even lanes: 1
-#pragma unroll
-    for (int q = 0; q < 16; ++q) w32r[q] = p ? w32(q) : make_float2(1.0f, 0.0f);
-    __syncthreads();
-
-    // ---------------- phase 1: forward spectra ----------------
-    {
-        float2 xin[16];
-        auto load_x = [&](int b) __attribute__((always_inline)) {
-            const long item = (first_window + wl) * (long)n_buoys + b;
-            if constexpr (U8) {
-                const uchar2* x = reinterpret_cast<const uchar2*>(iq_v) + item * kM;
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const uchar2 bb = x[q * 256 + u];
-                    xin[q] = make_float2((float)bb.x - 127.5f, (float)bb.y - 127.5f);
-                }
-            } else {
-                const float2* x = reinterpret_cast<const float2*>(iq_v) + item * kM;
-#pragma unroll
-                for (int q = 0; q < 16; ++q) xin[q] = x[q * 256 + u];
-            }
-        };
-        load_x(0);
-        for (int b = 0; b < n_buoys; ++b) {
-            float2 v[16];
-#pragma unroll
-            for (int q = 0; q < 16; ++q) v[q] = xin[q];
-            load_x(b + 1 < n_buoys ? b + 1 : b);   // next buoy's samples fly during this transform
-            float2* img = (b & 1) ? img1 : img0;
-            dft16_tw<true>(v, w32r);   // odd sub-transform input x*W32^q (W_L^u is folded into tw1)
-            mul_tw1(v, tw1);
-            xchg_a_write(img, v, t);
-            __syncthreads();
-            xchg_b_read(img, v, t);
-            dft16(v);
-            mul_tw2(v, tw2_lds, u & 15);
-            xchg_bc_write_b(img, v, t);
-            wave_lds_fence();
-            xchg_bc_read_c(img, v, t);
-            dft16(v);
-            float4* out = spec + (wbase + b) * (8 * kThreads);
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (!(AB & 32)) out[j * kThreads + t] = make_float4(v[2 * j].x * fwd_scale, v[2 * j].y * fwd_scale,
-                                                    v[2 * j + 1].x * fwd_scale, v[2 * j + 1].y * fwd_scale);
-        }
-    }
-    if (n_items <= 0) return;
-
-    // ---------------- phase 2: pairs ----------------
+    const float4* tw2row = reinterpret_cast<const float4*>(tw2_lds + (u & 15) * kTw2RowF2);
     const float sgn = p ? -1.0f : 1.0f;
     const int kbase = p ? (u - 1) : (u + kM - 1);
-    const long obase = (first_window + wl) * (long)n_pairs;
     const int hl = lane < 2 ? lane : lane - 60;            // halo row of lanes 0,1,62,63
     const bool is_halo = lane < 2 || lane >= 62;
-    float2 sa[16], sb[16];   // anchor X_i (multiplier) and streamed X_j, as 16 complex each
+    __syncthreads();
 
-    auto load_spec = [&](float2 (&d)[16], int b) __attribute__((always_inline)) {
-        const float4* x = spec + (wbase + b) * (8 * kThreads);
+    int seq = 0;         // transform counter: selects the exchange image
+    int npair = 0;       // pair counter: selects the record buffer
+    int pending = -1;    // output slot of the pair whose records await the next barrier
+
+    C16 sa, sb;   // anchor spectrum X_i and the streamed X_j (scalar arrays: see C16)
+
+    auto barrier_hook = [&]() __attribute__((always_inline)) {
+        if (!(dbg & 1)) __syncthreads();
+        if (!(dbg & 2) && pending >= 0 && wave == (seq & 7))
+            resolve_win(lane, red + ((npair - 1) & 1) * 8, halo + ((npair - 1) & 1) * (8 * 4 * 16), obase + pending,
+                        out_scale, lag_int, lag_frac, peak);
+        pending = -1;
+    };
+    // odd lanes: v[q] *= W32^q, the per-slot part of the odd sub-transform's W_L^n (in place)
+    auto mul_w32_odd = [&](float2 (&v)[16]) __attribute__((always_inline)) {
+        if (p) {
+#pragma unroll
+            for (int q = 1; q < 16; ++q) {
+                const float2 w = w32(q);
+                float x = v[q].x, y = v[q].y;   // scalars by value: keeps the array out of scratch
+                cmul_inplace(x, y, w.x, w.y);
+                v[q].x = x;
+                v[q].y = y;
+            }
+        }
+    };
+    // All global traffic of the loop goes through buffer descriptors held in SGPRs: address = SRD
+    // base + one shared 32-bit VGPR offset + an SGPR/immediate offset.  (With flat 64-bit addressing
+    // hipcc keeps ~100 VGPRs of loop-invariant addresses alive and spills the twiddles instead.)
+    const int samp_bytes = U8 ? 2 : 8;
+    const __amdgpu_buffer_rsrc_t xs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(iq_v)) + (first_window + wl) * (long)B * kM * samp_bytes, 0,
+        B * kM * samp_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ss = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<char*>(spec) + wbase * (long)(8 * kThreads * 16), 0, B * (8 * kThreads * 16), 0x00020000);
+    const int xoff = u * samp_bytes, soff = t * 16;
+    // raw window samples of buoy b into d (uint8 pairs stay packed in d[q].x until cvt_x)
+    auto load_x = [&](C16& d, int b) __attribute__((always_inline)) {
+        if constexpr (U8) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                d.re[q] = __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b16(xs, xoff, (b * kM + q * 256) * 2, 0));
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(xs, xoff, (b * kM + q * 256) * 8, 0);
+                d.set(q, __uint_as_float(r.x), __uint_as_float(r.y));   // (by value: see NOTE)
+            }
+        }
+    };
+    auto cvt_x = [&](C16& d) __attribute__((always_inline)) {
+        if constexpr (U8) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const unsigned r = __float_as_uint(d.re[q]);
+                d.set(q, (float)(r & 0xffu) - 127.5f, (float)(r >> 8) - 127.5f);
+            }
+        }
+    };
+    auto load_spec = [&](C16& d, int b) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float4 w = x[j * kThreads + t];
-            d[2 * j] = make_float2(w.x, w.y);
-            d[2 * j + 1] = make_float2(w.z, w.w);
+            const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(ss, soff, (b * 8 + j) * (kThreads * 16), 0);
+            d.set(2 * j, __uint_as_float(w.x), __uint_as_float(w.y));
+            d.set(2 * j + 1, __uint_as_float(w.z), __uint_as_float(w.w));
         }
     };
-
-    // Two pairs are in flight per loop trip (software pipeline, one workgroup barrier per trip):
-    //   pair B = it   : first half  (conj-multiply + DFT16, wave-local exchange, TW2 + DFT16, image write)
-    //   pair A = it-1 : second half (image read, TW1 + DFT16, W32, lane-pair butterfly, |.|^2, argmax)
-    // The two halves use different exchange images and are interleaved so that every LDS round trip
-    // of one pair is covered by ~200 independent VALU instructions of the other.
-    float2 va[16], vb[16];
-    const float4* tw2row = reinterpret_cast<const float4*>(tw2_lds + (u & 15) * kTw2RowF2);
-
-    // items are read one trip ahead with a scalar load at the very top of the trip, BEFORE any LDS
-    // access is issued (scalar loads share lgkmcnt with LDS: a wait for one drains the other).
-    PairItem cur = items[0];
-    PairItem nxt = items[n_items > 1 ? 1 : 0];
-    auto first_half_begin = [&]() __attribute__((always_inline)) {   // product + DFT16 (role C)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) vb[q] = make_float2(sb[q].y, sb[q].x);
-        dft16_tw<false>(vb, sa);
-        // keep the requests below the arithmetic that still reads sa/sb: the new values can then
-        // land in the same registers (no loop-carried copies), with a whole pair of latency cover.
-        // (Pure arithmetic is not ordered by sched_barrier at instruction selection: pin its results.)
-#pragma unroll
-        for (int q = 0; q < 16; q += 4)
-            asm volatile("" : "+v"(vb[q].x), "+v"(vb[q].y), "+v"(vb[q + 1].x), "+v"(vb[q + 1].y), "+v"(vb[q + 2].x),
-                         "+v"(vb[q + 2].y), "+v"(vb[q + 3].x), "+v"(vb[q + 3].y));
-        __builtin_amdgcn_sched_barrier(0);
-        if (!(AB & 16)) {
-        load_spec(sb, nxt.j);
-        if (cur.run == 1) load_spec(sa, nxt.i);    // last pair of this anchor's run
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    auto first_half_end = [&](float2* img) __attribute__((always_inline)) {    // TW2 + DFT16 (role B), publish
-        float2 w2[16];
+    auto store_spec = [&](const C16& d, int b) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float4 w = tw2row[j];
-            w2[2 * j] = make_float2(w.x, w.y);
-            w2[2 * j + 1] = make_float2(w.z, w.w);
+            // (opaque copies: hipcc otherwise widens these four scalar reads into overlapping 16-byte
+            // loads of the register array, which pins half of it in scratch memory)
+            float e0 = d.re[2 * j], e1 = d.im[2 * j], e2 = d.re[2 * j + 1], e3 = d.im[2 * j + 1];
+            asm volatile("" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3));
+            const u32x4 w = {__float_as_uint(e0), __float_as_uint(e1), __float_as_uint(e2), __float_as_uint(e3)};
+            // the whole byte offset goes into the VGPR offset: buffer STORES with a non-zero SGPR soffset
+            // corrupted the stored spectra on MI355X / ROCm 7.2 (nondeterministically; loads with an SGPR
+            // soffset are fine, and neither s_nop padding nor vmcnt(0) after the store cured it)
+            __builtin_amdgcn_raw_buffer_store_b128(w, ss, soff + (b * 8 + j) * (kThreads * 16), 0, 0);
         }
-        dft16_tw<true>(vb, w2);
-        if (!(AB & 8)) xchg_b_write(img, vb, t);
     };
-    float mag[16];
-    auto second_half_mid = [&]() __attribute__((always_inline)) {    // W32, lane-pair butterfly, |.|^2
+    // forward spectrum of the samples in x, in place (scaled by fwd_scale)
+    auto fwd = [&](C16& xc) __attribute__((always_inline)) {
+        float2* img = (seq & 1) ? img1 : img0;
+        float2 x[16];
 #pragma unroll
-        for (int q = 1; q < 16; ++q) va[q] = cmul(va[q], w32r[q]);
-        pair_fmac8(va[0].x, va[0].y, va[1].x, va[1].y, va[2].x, va[2].y, va[3].x, va[3].y, sgn);
-        pair_fmac8(va[4].x, va[4].y, va[5].x, va[5].y, va[6].x, va[6].y, va[7].x, va[7].y, sgn);
-        pair_fmac8(va[8].x, va[8].y, va[9].x, va[9].y, va[10].x, va[10].y, va[11].x, va[11].y, sgn);
-        pair_fmac8(va[12].x, va[12].y, va[13].x, va[13].y, va[14].x, va[14].y, va[15].x, va[15].y, sgn);
+        for (int q = 0; q < 16; ++q) x[q] = xc.get(q);
+        mul_w32_odd(x);            // odd sub-transform input x*W32^q (W_L^u is folded into tw1)
+        dft16(x);
+        mul_tw1(x, tw1);
+        if (!(dbg & 8)) xchg_a_write(img, x, t);
+        barrier_hook();
+        if (!(dbg & 8)) xchg_b_read(img, x, t);
+        dft16(x);
+        if (!(dbg & 4)) {
+        xchg_bc_write_b(img, x, t);
+        wave_lds_fence();
+        xchg_bc_read_c(img, x, t);
+        }
+        dft16_tw_row(x, tw2row);   // W_256^(n0*k1) as pre-twiddle of the last pass
 #pragma unroll
-        for (int q = 0; q < 16; ++q) mag[q] = fmaf(va[q].x, va[q].x, va[q].y * va[q].y);
+        for (int q = 0; q < 16; ++q) xc.set(q, x[q].x * fwd_scale, x[q].y * fwd_scale);
+        ++seq;
+    };
+    // one pair: anchor a (conjugated side, buoy i), stream s (buoy j); `prefetch` runs after the last
+    // read of a and s (their registers may be reloaded there, a whole pair ahead of their next use)
+    auto pair = [&](const C16& a, const C16& s, int out_idx, auto prefetch)
+                    __attribute__((always_inline)) {
+        float2* img = (seq & 1) ? img1 : img0;
+        const int rb = npair & 1;
+        float2 v[16];
+        // R = X_j conj(X_i), (im,re)-swapped == swap(X_j) * X_i: merged into the first radix-16 pass
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = make_float2(s.im[q], s.re[q]);
+        dft16_tw<false>(v, a);                   // k2 -> n0   (role C)
+#pragma unroll
+        for (int q = 0; q < 16; q += 4)          // pin: the requests below must follow the reads above
+            asm volatile("" : "+v"(v[q].x), "+v"(v[q].y), "+v"(v[q + 1].x), "+v"(v[q + 1].y), "+v"(v[q + 2].x),
+                         "+v"(v[q + 2].y), "+v"(v[q + 3].x), "+v"(v[q + 3].y));
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(dbg & 16)) prefetch();
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(dbg & 4)) {
+        xchg_bc_write_c(img, v, t);
+        wave_lds_fence();
+        xchg_bc_read_b(img, v, t);
+        }
+        dft16_tw_row(v, tw2row);                 // W_256^(n0*k1), k1 -> n1   (role B)
+        if (!(dbg & 8)) xchg_b_write(img, v, t);                 // own half-wave regions
+        barrier_hook();                          // the pair's only barrier
+        if (!(dbg & 8)) xchg_a_read(img, v, t);
+        dft16_tw<false>(v, tw1);                 // W_M^(u*k0) [* W_L^u odd], k0 -> n2   (role A)
+        mul_w32_odd(v);                          // odd lanes: * W32^q
+        // last radix-2 stage across the lane pair, up to a sign that |.| does not see:
+        // even lane e + o' = r[n], odd lane o' - e = -r[n+M]
+        pair_fmac8(v[0].x, v[0].y, v[1].x, v[1].y, v[2].x, v[2].y, v[3].x, v[3].y, sgn);
+        pair_fmac8(v[4].x, v[4].y, v[5].x, v[5].y, v[6].x, v[6].y, v[7].x, v[7].y, sgn);
+        pair_fmac8(v[8].x, v[8].y, v[9].x, v[9].y, v[10].x, v[10].y, v[11].x, v[11].y, sgn);
+        pair_fmac8(v[12].x, v[12].y, v[13].x, v[13].y, v[14].x, v[14].y, v[15].x, v[15].y, sgn);
+        float mag[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) mag[q] = fmaf(v[q].x, v[q].x, v[q].y * v[q].y);
         if (p && u == 0) mag[0] = -1.0f;         // lag -M is not part of the 'full' output
-    };
-    auto second_half_end = [&](int buf) __attribute__((always_inline)) {    // wave argmax, taps, publish
+        if (dbg & 2) {
+            float s = 0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) s += mag[q];
+            if (s == 12345.678f) lag_int[0] = 1;
+            pending = out_idx; ++seq; ++npair;
+            return;
+        }
         if (is_halo) {
-            float4* hp = reinterpret_cast<float4*>(halo + ((buf * 8 + wave) * 4 + hl) * 16);
+            float4* hp = reinterpret_cast<float4*>(halo + ((rb * 8 + wave) * 4 + hl) * 16);
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4)
                 hp[q4] = make_float4(mag[4 * q4], mag[4 * q4 + 1], mag[4 * q4 + 2], mag[4 * q4 + 3]);
@@ -709,62 +779,53 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
         const int seli = __builtin_bit_cast(int, sel);
         const float tapm = ls >= 2 ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(seli, ls >= 2 ? ls - 2 : 0)) : -2.0f;
         const float tapp = ls <= 61 ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(seli, ls <= 61 ? ls + 2 : 63)) : -2.0f;
-        if (lane == 0) red[buf * 8 + wave] = make_float4(wmax, __builtin_bit_cast(float, kw), tapm, tapp);
+        if (lane == 0) {
+            const u32x4 rec = {__float_as_uint(wmax), (unsigned)kw, __float_as_uint(tapm), __float_as_uint(tapp)};
+            *reinterpret_cast<u32x4*>(red + rb * 8 + wave) = rec;
+        }
+        pending = out_idx;
+        ++seq;
+        ++npair;
     };
+    auto out_of = [&](int i, int j) -> int { return i * B - (i * (i + 1)) / 2 + (j - i - 1); };
 
-    load_spec(sa, cur.i);
-    load_spec(sb, cur.j);
-    // prologue: first half of pair 0 (images/records alternate on the pair index)
-    first_half_begin();
-    xchg_bc_write_c(img0, vb, t);
-    wave_lds_fence();
-    xchg_bc_read_b(img0, vb, t);
-    first_half_end(img0);
-    __syncthreads();
-    int prev_out = cur.out;
-    for (int it = 1; it < n_items; ++it) {
-        cur = nxt;
-        nxt = items[it + 1 < n_items ? it + 1 : it];
-        {   // force the scalar load's wait here, ahead of the LDS traffic of this trip
-            int pin = nxt.i + nxt.j;
-            asm volatile("" : "+s"(pin));
-            (void)pin;
-        }
-        float2* imgA = (it & 1) ? img0 : img1;   // pair it-1
-        float2* imgB = (it & 1) ? img1 : img0;   // pair it
-        if (!(AB & 8)) xchg_a_read(imgA, va, t);                // A: 16 LDS reads in flight ...
-        first_half_begin();                      // B: ... under ~200 VALU + the next pair's global loads
-        if (!(AB & 4)) xchg_bc_write_c(imgB, vb, t);            // B: wave-local exchange, writes ...
-        dft16_tw<false>(va, tw1);                // A: ... under TW1 + DFT16 (k0 -> n2)
-        if (!(AB & 4)) {
-        wave_lds_fence();
-        xchg_bc_read_b(imgB, vb, t);             // B: ... reads ...
-        }
-        second_half_mid();                       // A: ... under W32 / butterfly / |.|^2
-        first_half_end(imgB);                    // B: TW2 + DFT16, image write ...
-        if (!(AB & 2)) second_half_end((it - 1) & 1);           // A: ... under the argmax
-        else { float s = 0;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) s += mag[q];
-            if (s == 12345.678f) lag_int[0] = 1; }
-        if (!(AB & 1)) __syncthreads();
-        if (!(AB & 2) && wave == (it & 7))
-            resolve_win(lane, red + ((it - 1) & 1) * 8, halo + ((it - 1) & 1) * (8 * 4 * 16), obase + prev_out,
-                        out_scale, lag_int, lag_frac, peak);
-        prev_out = cur.out;
+    // ---- anchor 0: X_0 goes straight into the anchor registers (never stored); every other X_e is
+    // transformed once, stored once for the later anchors, and used at once from registers for (0,e)
+    load_x(sa, 0);
+    cvt_x(sa);
+    fwd(sa);
+    if (B > 1) load_x(sb, 1);
+    for (int e = 1; e < B; ++e) {
+        cvt_x(sb);
+        fwd(sb);
+        store_spec(sb, e);
+        pair(sa, sb, out_of(0, e), [&]() __attribute__((always_inline)) {
+            if (e + 1 < B) {
+                load_x(sb, e + 1);
+            } else if (B > 2) {        // next anchor 1 streams downwards from B-1: X_{B-1} is L2-hot
+                load_spec(sa, 1);
+                load_spec(sb, B - 1);
+            }
+        });
     }
-    {   // epilogue: second half of the last pair
-        const int last = n_items - 1;
-        float2* imgA = (last & 1) ? img1 : img0;
-        xchg_a_read(imgA, va, t);
-        dft16_tw<false>(va, tw1);
-        second_half_mid();
-        second_half_end(last & 1);
-        __syncthreads();
-        if (wave == 0)
-            resolve_win(lane, red + (last & 1) * 8, halo + (last & 1) * (8 * 4 * 16), obase + prev_out, out_scale,
-                        lag_int, lag_frac, peak);
+    // ---- anchors 1..B-2: the stream direction alternates (odd anchors walk j down, even ones up), so
+    // the first spectra an anchor streams are the ones the previous anchor touched last (L2 hits)
+    for (int i = 1; i + 1 < B; ++i) {
+        const int n = B - 1 - i;                 // pairs of this anchor
+        for (int s = 0; s < n; ++s) {
+            const int j = (i & 1) ? (B - 1 - s) : (i + 1 + s);
+            pair(sa, sb, out_of(i, j), [&]() __attribute__((always_inline)) {
+                if (s + 1 < n) {
+                    load_spec(sb, (i & 1) ? (j - 1) : (j + 1));
+                } else if (i + 2 < B) {
+                    load_spec(sa, i + 1);
+                    load_spec(sb, ((i + 1) & 1) ? (B - 1) : (i + 2));
+                }
+            });
+        }
     }
+    seq = 0;   // any wave may resolve the last pair; take wave 0
+    barrier_hook();
 }
 
 #define RMX_PAIR_ARGS                                                                                         \
@@ -808,6 +869,7 @@ struct rmx_ctx {
     // cached pair plan
     std::vector<int32_t> plan_pairs;
     int plan_n_pairs = -1, plan_n_parts = 0, plan_ppb = 0;
+    bool plan_all_pairs = false;   // the plan is the default list: all i<j in nested-loop order
     // timing
     std::vector<hipEvent_t> ev;
     std::vector<int> ev_kind;  // 0 fwd, 1 pair (per launch: ev[2k], ev[2k+1])
@@ -903,6 +965,14 @@ static int build_plan(rmx_ctx* c, const int32_t* pairs, int n_pairs) {
     RMX_HIP(c, hipMalloc((void**)&c->d_part_begin, sizeof(int) * (size_t)(n_parts + 1)));
     RMX_HIP(c, hipMemcpy(c->d_items, items.data(), sizeof(PairItem) * (size_t)n_pairs, hipMemcpyHostToDevice));
     RMX_HIP(c, hipMemcpy(c->d_part_begin, pb.data(), sizeof(int) * (size_t)(n_parts + 1), hipMemcpyHostToDevice));
+    {
+        bool all = n_pairs == c->n_buoys * (c->n_buoys - 1) / 2;
+        int q = 0;
+        for (int i = 0; all && i < c->n_buoys; ++i)
+            for (int j = i + 1; j < c->n_buoys; ++j, ++q)
+                if (pl[2 * q] != i || pl[2 * q + 1] != j) { all = false; break; }
+        c->plan_all_pairs = all;
+    }
     c->plan_pairs.swap(pl);
     c->plan_n_pairs = n_pairs;
     c->plan_n_parts = n_parts;
@@ -960,15 +1030,10 @@ int rmx_create(rmx_ctx** out, int device_id, int n_buoys, int n_samples, int max
         RMX_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         c->own_stream = true;
         const char* env = getenv("RMX_CHUNK_WINDOWS");
-        int chunk = env ? atoi(env) : 4096;
+        int chunk = env ? atoi(env) : 512;
         if (chunk < 8) chunk = 8;
         chunk = (chunk + 7) & ~7;
         if (chunk > max_windows) chunk = max_windows;
-        {   // spectra scratch = chunk * B * 64 KiB: keep it under 8 GiB
-            const long per_win = (long)n_buoys * (8 * kThreads) * (long)sizeof(float4);
-            const long cap = (8L << 30) / per_win;
-            if (chunk > cap) chunk = (int)(cap > 8 ? (cap & ~7L) : 8);
-        }
         c->chunk_windows = chunk;
         c->spec_bytes = (size_t)chunk * n_buoys * (8 * kThreads) * sizeof(float4);
         RMX_HIP(c, hipMalloc((void**)&c->d_spec, c->spec_bytes));
@@ -1134,16 +1199,16 @@ int rmx_xcorr_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pa
     }
     for (int w0 = 0; w0 < n_windows; w0 += c->chunk_windows) {
         const int wc = (n_windows - w0 < c->chunk_windows) ? n_windows - w0 : c->chunk_windows;
-        if (c->fused) {
+        if (c->fused && c->plan_all_pairs) {
             if (c->timing) RMX_HIP(c, hipEventRecord(c->ev[c->ev_used], c->stream));
             if (u8)
                 hipLaunchKernelGGL(k_win<true>, dim3(wc), dim3(kThreads), kLdsWinBytes, c->stream, d_iq, c->d_spec,
-                                   c->d_tw1, c->d_tw2, c->d_items, n_pairs, c->n_buoys, n_pairs, (long)w0, fwd_scale,
-                                   out_scale, d_lag, d_frac, d_peak);
+                                   c->d_tw1, c->d_tw2, c->n_buoys, (long)w0, fwd_scale, out_scale, d_lag, d_frac,
+                                   d_peak, c->dbg);
             else
                 hipLaunchKernelGGL(k_win<false>, dim3(wc), dim3(kThreads), kLdsWinBytes, c->stream, d_iq, c->d_spec,
-                                   c->d_tw1, c->d_tw2, c->d_items, n_pairs, c->n_buoys, n_pairs, (long)w0, fwd_scale,
-                                   out_scale, d_lag, d_frac, d_peak);
+                                   c->d_tw1, c->d_tw2, c->n_buoys, (long)w0, fwd_scale, out_scale, d_lag, d_frac,
+                                   d_peak, c->dbg);
             RMX_HIP(c, hipGetLastError());
             if (c->timing) {
                 RMX_HIP(c, hipEventRecord(c->ev[c->ev_used + 1], c->stream));

@@ -92,7 +92,10 @@ def test_custom_pairs_and_antisymmetry(xc):
     assert np.all(np.abs(lf + rf) <= TOL) and np.allclose(pk, rpk, rtol=1e-5)
     allp = [tuple(p) for p in xc.pair_list(5)]
     cols = [allp.index(tuple(p)) for p in fwd]
-    assert np.array_equal(li, lall[:, cols]) and np.array_equal(lf, fall[:, cols])
+    # a custom list runs the two-kernel path, the default list the fused window kernel: same lags,
+    # last-bit differences in the fraction allowed
+    assert np.array_equal(li, lall[:, cols]) and np.all(np.abs(lf - fall[:, cols]) <= TOL)
+    assert np.allclose(pk, pall[:, cols], rtol=1e-5)
     # against the oracle with the same custom list
     oi, of_, op = orc.xcorr_batch_literal(iq, fwd)
     _assert_parity(li, lf, pk, oi, of_, op)

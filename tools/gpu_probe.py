@@ -64,6 +64,6 @@ def timing(W=4096, B=8, N=4096, chunk=None, ppb=None, reps=5, resident=1, dbg=0,
 
 if __name__ == "__main__":
     print("lib:", xcorr.library_path(), "devices:", xcorr.device_count())
-    if "ablate" not in xcorr.library_path():
-        parity()
+    parity()
     timing(chunk=4096)
+    timing(chunk=512)
