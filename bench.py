@@ -171,6 +171,17 @@ def main():
         elapsed = float(t.item())
     ms_per_step = elapsed * 1e3 / args.steps
 
+    # PCIe-inclusive rate of the same step through the host-pointer entry of the C ABI (reported in
+    # DESIGN.md, never `value`): pageable numpy in, numpy out
+    host_ms = None
+    if rank == 0 and n_gpus == 1:
+        xh = x.cpu().numpy().view(np.complex64).reshape(W, B, N)
+        eng.correlate(xh[:64])
+        th = time.perf_counter()
+        eng.correlate(xh)
+        host_ms = (time.perf_counter() - th) * 1e3
+        del xh
+
     # host-side gather of the lag scalars (the only exchange of the multi-GPU path)
     li, lf, pk = lag.cpu().numpy(), frac.cpu().numpy(), peak.cpu().numpy()
     gathered = gather_lags(li, lf, pk) if world > 1 else (li, lf, pk)
@@ -223,6 +234,7 @@ def main():
                          "fwd_kernel_ms_per_step": fwd_ms / n_meas,
                          "pair_kernel_ms_per_step": pair_ms / n_meas,
                          "whole_path_frac": (W * P * alg_bytes_per_pw) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "host_path_ms_per_step": host_ms,
             "cpu_baseline": cpu,
             "parity": parity,
         }

@@ -1030,10 +1030,15 @@ int rmx_create(rmx_ctx** out, int device_id, int n_buoys, int n_samples, int max
         RMX_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         c->own_stream = true;
         const char* env = getenv("RMX_CHUNK_WINDOWS");
-        int chunk = env ? atoi(env) : 512;
+        int chunk = env ? atoi(env) : 4096;
         if (chunk < 8) chunk = 8;
         chunk = (chunk + 7) & ~7;
         if (chunk > max_windows) chunk = max_windows;
+        {   // spectra scratch = chunk * B * 64 KiB: keep it under 8 GiB
+            const long per_win = (long)n_buoys * (8 * kThreads) * (long)sizeof(float4);
+            const long cap = (8L << 30) / per_win;
+            if (chunk > cap) chunk = (int)(cap > 8 ? (cap & ~7L) : 8);
+        }
         c->chunk_windows = chunk;
         c->spec_bytes = (size_t)chunk * n_buoys * (8 * kThreads) * sizeof(float4);
         RMX_HIP(c, hipMalloc((void**)&c->d_spec, c->spec_bytes));
