@@ -1,0 +1,331 @@
+// generic_path.hpp -- the same path for every power-of-two window length N (16 .. 4 Mi samples).
+//
+// N = 4096 (BASELINE cfg3/cfg4) has the register/LDS-resident radix-16 kernels of rmx_hip.hip.  All
+// other lengths run here: simpler kernels, same definition, same output contract.
+//   L = 2N <= 8192   one workgroup per transform, the whole zero-padded window in LDS:
+//                      g_fwd_small   (window, buoy)  : radix-2 DIF, spectrum left in bit-reversed order
+//                      g_pair_small  (window, pair)  : X_j conj(X_i) -> radix-2 DIT (takes bit-reversed
+//                                                      input, natural output) -> |.|, argmax, parabola
+//   L = 2N  > 8192   four-step transform through HBM, L = L1 x L2 (both <= 4096), every pass a batch
+//                    of LDS row transforms between tiled transposes; the spectrum stays in the
+//                    "digit-reversed" order the forward pass leaves it in (the product is pointwise
+//                    and the inverse pass undoes the same permutation):
+//                      forward : T, rows(L1, DIF) * W_L^(n2 k1), T, rows(L2, DIF)
+//                      inverse : rows(L2, DIT) * W_L^-(n2 k1), T, rows(L1, DIT), T  -> r[0..L) natural
+//                      g_absmax (partial argmax in 'full' order) + g_final (reduce, 3 taps, parabola)
+// Twiddles: W_R^k tables per row length computed in double on the host; the large W_L^(a*b) factor of
+// the four-step is the product of two table entries (a*b mod L split into high and low digits).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <vector>
+
+namespace rmx {
+namespace gen {
+
+constexpr int kGThreads = 256;
+
+__device__ __forceinline__ float2 g_cmul(float2 a, float2 b) {
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ float2 g_cmulc(float2 a, float2 b) {   // a * conj(b)
+    return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+}
+
+// In-place radix-2 transforms of one row of R = 2^logR points held in LDS; tw[k] = W_R^k, k < R/2.
+// DIF: natural in -> bit-reversed out (forward, W = exp(-2 pi i / R)).
+__device__ __forceinline__ void lds_dif(float2* x, int logR, const float2* __restrict__ tw, int tid, int nthr) {
+    const int half_n = 1 << (logR - 1);
+    for (int s = logR - 1; s >= 0; --s) {
+        const int half = 1 << s;
+        for (int i = tid; i < half_n; i += nthr) {
+            const int lo = i & (half - 1);
+            const int j = ((i >> s) << (s + 1)) | lo;
+            const float2 a = x[j], b = x[j + half];
+            const float2 w = tw[lo << (logR - 1 - s)];
+            x[j] = make_float2(a.x + b.x, a.y + b.y);
+            x[j + half] = g_cmul(make_float2(a.x - b.x, a.y - b.y), w);
+        }
+        __syncthreads();
+    }
+}
+// DIT with conjugated twiddles: bit-reversed in -> natural out (inverse, unnormalised).
+__device__ __forceinline__ void lds_dit_inv(float2* x, int logR, const float2* __restrict__ tw, int tid, int nthr) {
+    const int half_n = 1 << (logR - 1);
+    for (int s = 0; s < logR; ++s) {
+        const int half = 1 << s;
+        for (int i = tid; i < half_n; i += nthr) {
+            const int lo = i & (half - 1);
+            const int j = ((i >> s) << (s + 1)) | lo;
+            const float2 a = x[j];
+            const float2 b = g_cmulc(x[j + half], tw[lo << (logR - 1 - s)]);
+            x[j] = make_float2(a.x + b.x, a.y + b.y);
+            x[j + half] = make_float2(a.x - b.x, a.y - b.y);
+        }
+        __syncthreads();
+    }
+}
+
+// 'full' order index (lag ascending from -(N-1)) of circular index m of an L = 2N point correlation;
+// m == N (lag -N) is not part of the 'full' output: returns -1.
+__device__ __forceinline__ int full_index(int m, int N) { return m < N ? m + N - 1 : (m == N ? -1 : m - N - 1); }
+__device__ __forceinline__ int circ_index(int k, int N) { return k >= N - 1 ? k - (N - 1) : k + N + 1; }
+
+// workgroup argmax of (value, lowest index): every thread passes its best candidate
+__device__ __forceinline__ void block_argmax(float& v, int& k, float* sv, int* sk, int tid, int nthr) {
+    sv[tid] = v;
+    sk[tid] = k;
+    __syncthreads();
+    for (int s = nthr >> 1; s > 0; s >>= 1) {
+        if (tid < s) {
+            const float ov = sv[tid + s];
+            const int ok = sk[tid + s];
+            if (ov > sv[tid] || (ov == sv[tid] && ok < sk[tid])) { sv[tid] = ov; sk[tid] = ok; }
+        }
+        __syncthreads();
+    }
+    v = sv[0];
+    k = sk[0];
+    __syncthreads();
+}
+
+__device__ __forceinline__ float parabola(float a, float b, float c) {
+    const double den = (double)a - 2.0 * (double)b + (double)c;
+    return den == 0.0 ? 0.0f : (float)(0.5 * ((double)a - (double)c) / den);
+}
+
+// ---- small path -------------------------------------------------------------------------------
+// spectrum layout: [item][L] complex, bit-reversed order, scaled by `scale`
+template <bool U8>
+__global__ __launch_bounds__(kGThreads) void g_fwd_small(const void* __restrict__ iq, float2* __restrict__ spec,
+                                                         const float2* __restrict__ tw, int N, int logL,
+                                                         long first_item, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char gsm[];
+    float2* x = reinterpret_cast<float2*>(gsm);
+    const int L = 1 << logL, tid = threadIdx.x;
+    const long item = first_item + blockIdx.x;
+    for (int n = tid; n < L; n += kGThreads) {
+        float2 v = make_float2(0.f, 0.f);
+        if (n < N) {
+            if constexpr (U8) {
+                const uchar2 b = reinterpret_cast<const uchar2*>(iq)[item * N + n];
+                v = make_float2((float)b.x - 127.5f, (float)b.y - 127.5f);
+            } else {
+                v = reinterpret_cast<const float2*>(iq)[item * N + n];
+            }
+        }
+        x[n] = v;
+    }
+    __syncthreads();
+    lds_dif(x, logL, tw, tid, kGThreads);
+    float2* out = spec + (long)blockIdx.x * L;
+    for (int n = tid; n < L; n += kGThreads) out[n] = make_float2(x[n].x * scale, x[n].y * scale);
+}
+
+struct GPair {
+    int i, j;
+};
+
+__global__ __launch_bounds__(kGThreads) void g_pair_small(const float2* __restrict__ spec,
+                                                          const float2* __restrict__ tw,
+                                                          const GPair* __restrict__ pairs, int n_pairs,
+                                                          int n_buoys, int N, int logL, long first_window,
+                                                          float out_scale, int* __restrict__ lag_int,
+                                                          float* __restrict__ lag_frac, float* __restrict__ peak) {
+    extern __shared__ __attribute__((aligned(16))) char gsm[];
+    float2* x = reinterpret_cast<float2*>(gsm);
+    const int L = 1 << logL, tid = threadIdx.x;
+    float* sv = reinterpret_cast<float*>(gsm + (size_t)L * 8);
+    int* sk = reinterpret_cast<int*>(sv + kGThreads);
+    const int wl = blockIdx.x / n_pairs, q = blockIdx.x % n_pairs;
+    const GPair pr = pairs[q];
+    const float2* xi = spec + ((long)wl * n_buoys + pr.i) * L;
+    const float2* xj = spec + ((long)wl * n_buoys + pr.j) * L;
+    for (int n = tid; n < L; n += kGThreads) x[n] = g_cmulc(xj[n], xi[n]);   // X_j conj(X_i)
+    __syncthreads();
+    lds_dit_inv(x, logL, tw, tid, kGThreads);
+    float best = -1.0f;
+    int bk = 0x7fffffff;
+    for (int m = tid; m < L; m += kGThreads) {
+        const int k = full_index(m, N);
+        if (k < 0) continue;
+        const float v = x[m].x * x[m].x + x[m].y * x[m].y;
+        if (v > best || (v == best && k < bk)) { best = v; bk = k; }
+    }
+    block_argmax(best, bk, sv, sk, tid, kGThreads);
+    if (tid == 0) {
+        const float b = sqrtf(best) * out_scale;
+        float frac = 0.0f;
+        if (bk > 0 && bk < 2 * N - 2) {
+            const float2 ra = x[circ_index(bk - 1, N)], rc = x[circ_index(bk + 1, N)];
+            frac = parabola(sqrtf(ra.x * ra.x + ra.y * ra.y) * out_scale, b,
+                            sqrtf(rc.x * rc.x + rc.y * rc.y) * out_scale);
+        }
+        const long o = (first_window + wl) * (long)n_pairs + q;
+        lag_int[o] = bk - (N - 1);
+        lag_frac[o] = frac;
+        peak[o] = b;
+    }
+}
+
+// ---- large path -------------------------------------------------------------------------------
+// batched tiled transpose: in [batch][rows][cols] -> out [batch][cols][rows]
+__global__ void g_transpose(const float2* __restrict__ in, float2* __restrict__ out, int rows, int cols) {
+    __shared__ float2 tile[32][33];
+    const long boff = (long)blockIdx.z * rows * cols;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int r = threadIdx.y; r < 32; r += 8)
+        tile[r][threadIdx.x] = in[boff + (long)(r0 + r) * cols + c0 + threadIdx.x];
+    __syncthreads();
+    for (int c = threadIdx.y; c < 32; c += 8)
+        out[boff + (long)(c0 + c) * rows + r0 + threadIdx.x] = tile[threadIdx.x][c];
+}
+
+__device__ __forceinline__ int brev(int v, int bits) { return (int)(__brev((unsigned)v) >> (32 - bits)); }
+
+// W_L^(m), m in [0, L): product of the two host tables (hi digit, lo digit)
+__device__ __forceinline__ float2 big_tw(long m, int lo_bits, const float2* __restrict__ thi,
+                                         const float2* __restrict__ tlo) {
+    return g_cmul(thi[m >> lo_bits], tlo[m & ((1L << lo_bits) - 1)]);
+}
+
+// MODE 0: rows are the zero-padded window itself transposed: handled by the caller (plain rows)
+// Row transforms of length R over a [batch * n_rows][R] array, in place.
+//   FWD = true : DIF; then (TW) multiply position q by W_L^(row_in_batch * brev(q))
+//   FWD = false: DIT inverse; then (TW) multiply position n by conj W_L^(n * brev(row_in_batch))
+template <bool FWD, bool TW>
+__global__ __launch_bounds__(kGThreads) void g_rows(float2* __restrict__ data, const float2* __restrict__ tw, int logR,
+                                                    int n_rows, int row_bits, long Ltot, int lo_bits,
+                                                    const float2* __restrict__ thi,
+                                                    const float2* __restrict__ tlo, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char gsm[];
+    float2* x = reinterpret_cast<float2*>(gsm);
+    const int R = 1 << logR, tid = threadIdx.x;
+    float2* row = data + (long)blockIdx.x * R;
+    const int rib = blockIdx.x % n_rows;   // row index inside its batch element
+    for (int n = tid; n < R; n += kGThreads) x[n] = row[n];
+    __syncthreads();
+    if (FWD) lds_dif(x, logR, tw, tid, kGThreads); else lds_dit_inv(x, logR, tw, tid, kGThreads);
+    for (int n = tid; n < R; n += kGThreads) {
+        float2 v = x[n];
+        if (TW) {
+            const long m = FWD ? ((long)rib * brev(n, logR)) % Ltot : ((long)n * brev(rib, row_bits)) % Ltot;
+            const float2 w = big_tw(m, lo_bits, thi, tlo);
+            v = FWD ? g_cmul(v, w) : g_cmulc(v, w);
+        }
+        row[n] = make_float2(v.x * scale, v.y * scale);
+    }
+}
+
+// zero-padded window as the [L1][L2] matrix, transposed on the fly: out[n2][n1] = x[n1*L2 + n2] (0 past N)
+template <bool U8>
+__global__ void g_load_transposed(const void* __restrict__ iq, float2* __restrict__ out, int N, int L1, int L2,
+                                  long first_item) {
+    __shared__ float2 tile[32][33];
+    const long item = first_item + blockIdx.z;
+    const long ooff = (long)blockIdx.z * L1 * L2;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;   // in: rows n1, cols n2
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const long n = (long)(r0 + r) * L2 + c0 + threadIdx.x;
+        float2 v = make_float2(0.f, 0.f);
+        if (n < N) {
+            if constexpr (U8) {
+                const uchar2 b = reinterpret_cast<const uchar2*>(iq)[item * N + n];
+                v = make_float2((float)b.x - 127.5f, (float)b.y - 127.5f);
+            } else {
+                v = reinterpret_cast<const float2*>(iq)[item * N + n];
+            }
+        }
+        tile[r][threadIdx.x] = v;
+    }
+    __syncthreads();
+    for (int c = threadIdx.y; c < 32; c += 8)
+        out[ooff + (long)(c0 + c) * L1 + r0 + threadIdx.x] = tile[threadIdx.x][c];
+}
+
+// prod[slot][m] = X_j[m] conj(X_i[m])
+__global__ void g_product(const float2* __restrict__ spec, float2* __restrict__ prod,
+                          const GPair* __restrict__ pairs, int n_pairs, int n_buoys, long L) {
+    const int slot = blockIdx.y;   // window-in-chunk * n_pairs + pair
+    const int wl = slot / n_pairs, q = slot % n_pairs;
+    const GPair pr = pairs[q];
+    const float2* xi = spec + ((long)wl * n_buoys + pr.i) * L;
+    const float2* xj = spec + ((long)wl * n_buoys + pr.j) * L;
+    float2* o = prod + (long)slot * L;
+    for (long m = (long)blockIdx.x * blockDim.x + threadIdx.x; m < L; m += (long)gridDim.x * blockDim.x)
+        o[m] = g_cmulc(xj[m], xi[m]);
+}
+
+// partial argmax of |r|^2 in 'full' order: grid (parts, slots)
+__global__ __launch_bounds__(kGThreads) void g_absmax(const float2* __restrict__ r, int N, float* __restrict__ pv,
+                                                      int* __restrict__ pk) {
+    __shared__ float sv[kGThreads];
+    __shared__ int sk[kGThreads];
+    const long L = 2L * N;
+    const float2* x = r + (long)blockIdx.y * L;
+    float best = -1.0f;
+    int bk = 0x7fffffff;
+    for (long m = (long)blockIdx.x * kGThreads + threadIdx.x; m < L; m += (long)gridDim.x * kGThreads) {
+        const int k = full_index((int)m, N);
+        if (k < 0) continue;
+        const float2 e = x[m];
+        const float v = e.x * e.x + e.y * e.y;
+        if (v > best || (v == best && k < bk)) { best = v; bk = k; }
+    }
+    block_argmax(best, bk, sv, sk, threadIdx.x, kGThreads);
+    if (threadIdx.x == 0) {
+        pv[(long)blockIdx.y * gridDim.x + blockIdx.x] = best;
+        pk[(long)blockIdx.y * gridDim.x + blockIdx.x] = bk;
+    }
+}
+
+__global__ void g_final(const float2* __restrict__ r, int N, const float* __restrict__ pv, const int* __restrict__ pk,
+                        int parts, int n_slots, long out_base, float out_scale, int* __restrict__ lag_int,
+                        float* __restrict__ lag_frac, float* __restrict__ peak) {
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= n_slots) return;
+    float best = -1.0f;
+    int bk = 0x7fffffff;
+    for (int p = 0; p < parts; ++p) {
+        const float v = pv[(long)slot * parts + p];
+        const int k = pk[(long)slot * parts + p];
+        if (v > best || (v == best && k < bk)) { best = v; bk = k; }
+    }
+    const float2* x = r + (long)slot * 2L * N;
+    const float b = sqrtf(best) * out_scale;
+    float frac = 0.0f;
+    if (bk > 0 && bk < 2 * N - 2) {
+        const float2 ra = x[circ_index(bk - 1, N)], rc = x[circ_index(bk + 1, N)];
+        frac = parabola(sqrtf(ra.x * ra.x + ra.y * ra.y) * out_scale, b, sqrtf(rc.x * rc.x + rc.y * rc.y) * out_scale);
+    }
+    lag_int[out_base + slot] = bk - (N - 1);
+    lag_frac[out_base + slot] = frac;
+    peak[out_base + slot] = b;
+}
+
+// ---- host-side tables ---------------------------------------------------------------------------
+inline void make_row_table(std::vector<float2>& t, int R) {   // W_R^k, k < R/2
+    t.resize(R / 2 > 0 ? R / 2 : 1);
+    for (int k = 0; k < R / 2; ++k) {
+        const double a = -6.283185307179586476925286766559 * (double)k / (double)R;
+        t[k] = make_float2((float)std::cos(a), (float)std::sin(a));
+    }
+    if (R / 2 == 0) t[0] = make_float2(1.f, 0.f);
+}
+inline void make_big_tables(std::vector<float2>& thi, std::vector<float2>& tlo, long L, int lo_bits) {
+    const long nlo = 1L << lo_bits, nhi = (L + nlo - 1) / nlo;
+    tlo.resize(nlo);
+    thi.resize(nhi);
+    for (long j = 0; j < nlo; ++j) {
+        const double a = -6.283185307179586476925286766559 * (double)j / (double)L;
+        tlo[j] = make_float2((float)std::cos(a), (float)std::sin(a));
+    }
+    for (long i = 0; i < nhi; ++i) {
+        const double a = -6.283185307179586476925286766559 * (double)(i * nlo) / (double)L;
+        thi[i] = make_float2((float)std::cos(a), (float)std::sin(a));
+    }
+}
+
+}  // namespace gen
+}  // namespace rmx

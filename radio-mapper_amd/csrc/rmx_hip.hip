@@ -25,6 +25,7 @@
 
 #include "../../include/rmx.h"
 #include "fft_r16.hpp"
+#include "generic_path.hpp"
 
 namespace rmx {
 
@@ -866,6 +867,17 @@ struct rmx_ctx {
     void* d_in = nullptr;      size_t d_in_bytes = 0;
     int* d_lag = nullptr;      float* d_frac = nullptr;  float* d_peak = nullptr;  size_t d_out_elems = 0;
     size_t spec_bytes = 0, scratch_bytes = 0;
+    // generic path (n_samples != 4096): see generic_path.hpp
+    bool generic = false;
+    int g_logL = 0, g_logL1 = 0, g_logL2 = 0, g_lo_bits = 0, g_chunk = 0;
+    float2 *g_tw = nullptr, *g_tw1 = nullptr, *g_tw2 = nullptr, *g_thi = nullptr, *g_tlo = nullptr;
+    float2 *g_spec = nullptr, *g_tmp = nullptr, *g_prod = nullptr;
+    float* g_pv = nullptr;
+    int* g_pk = nullptr;
+    rmx::gen::GPair* g_pairs = nullptr;
+    long g_slots_alloc = 0;
+    int g_pairs_n = -1;
+    std::vector<int32_t> g_pairs_plan;
     // cached pair plan
     std::vector<int32_t> plan_pairs;
     int plan_n_pairs = -1, plan_n_parts = 0, plan_ppb = 0;
@@ -982,6 +994,150 @@ static int build_plan(rmx_ctx* c, const int32_t* pairs, int n_pairs) {
 
 }  // namespace rmx
 
+namespace rmx {
+
+static int upload(rmx_ctx* c, float2** dst, const std::vector<float2>& v) {
+    RMX_HIP(c, hipMalloc((void**)dst, v.size() * sizeof(float2)));
+    RMX_HIP(c, hipMemcpy(*dst, v.data(), v.size() * sizeof(float2), hipMemcpyHostToDevice));
+    c->scratch_bytes += v.size() * sizeof(float2);
+    return RMX_OK;
+}
+
+static int generic_init(rmx_ctx* c) {
+    using namespace gen;
+    c->generic = true;
+    int logn = 0;
+    while ((1 << logn) < c->n_samples) ++logn;
+    c->g_logL = logn + 1;
+    const long L = 1L << c->g_logL;
+    const int all_pairs = c->n_buoys * (c->n_buoys - 1) / 2;
+    std::vector<float2> t;
+    if (L <= 8192) {
+        make_row_table(t, (int)L);
+        int rc = upload(c, &c->g_tw, t);
+        if (rc) return rc;
+        RMX_HIP(c, hipFuncSetAttribute((const void*)g_pair_small, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)(L * 8 + kGThreads * 8)));
+    } else {
+        c->g_logL1 = (c->g_logL + 1) / 2;
+        c->g_logL2 = c->g_logL - c->g_logL1;
+        c->g_lo_bits = (c->g_logL + 1) / 2;
+        make_row_table(t, 1 << c->g_logL1);
+        int rc = upload(c, &c->g_tw1, t);
+        if (rc) return rc;
+        make_row_table(t, 1 << c->g_logL2);
+        rc = upload(c, &c->g_tw2, t);
+        if (rc) return rc;
+        std::vector<float2> thi, tlo;
+        make_big_tables(thi, tlo, L, c->g_lo_bits);
+        rc = upload(c, &c->g_thi, thi);
+        if (rc) return rc;
+        rc = upload(c, &c->g_tlo, tlo);
+        if (rc) return rc;
+    }
+    // windows per chunk: spectra (B*L) + products (P*L) + work buffer, 8 bytes each, under ~3 GiB
+    const long per_win = (long)(c->n_buoys + 2L * (all_pairs > c->n_buoys ? all_pairs : c->n_buoys)) * L * 8;
+    long chunk = (3L << 30) / per_win;
+    if (chunk < 1) chunk = 1;
+    if (chunk > c->max_windows) chunk = c->max_windows;
+    if (chunk > 4096) chunk = 4096;
+    c->g_chunk = (int)chunk;
+    return RMX_OK;
+}
+
+static int generic_ensure(rmx_ctx* c, int n_pairs) {
+    using namespace gen;
+    const long L = 1L << c->g_logL;
+    const long items = (long)c->g_chunk * c->n_buoys, slots = (long)c->g_chunk * n_pairs;
+    if (!c->g_spec) {
+        RMX_HIP(c, hipMalloc((void**)&c->g_spec, items * L * 8));
+        c->scratch_bytes += items * L * 8;
+    }
+    if (L > 8192) {
+        // (re)allocate the pair-dependent buffers when the pair count grows
+        if (slots > c->g_slots_alloc) {
+            if (c->g_prod) { (void)hipFree(c->g_prod); c->g_prod = nullptr; }
+            if (c->g_tmp) { (void)hipFree(c->g_tmp); c->g_tmp = nullptr; }
+            if (c->g_pv) { (void)hipFree(c->g_pv); c->g_pv = nullptr; }
+            if (c->g_pk) { (void)hipFree(c->g_pk); c->g_pk = nullptr; }
+            c->g_slots_alloc = 0;
+            const long big = items > slots ? items : slots;
+            RMX_HIP(c, hipMalloc((void**)&c->g_prod, slots * L * 8));
+            RMX_HIP(c, hipMalloc((void**)&c->g_tmp, big * L * 8));
+            RMX_HIP(c, hipMalloc((void**)&c->g_pv, slots * 64 * sizeof(float)));
+            RMX_HIP(c, hipMalloc((void**)&c->g_pk, slots * 64 * sizeof(int)));
+            c->g_slots_alloc = slots;
+        }
+    }
+    if (c->g_pairs_n == n_pairs && c->g_pairs_plan == c->plan_pairs) return RMX_OK;
+    if (c->g_pairs) { (void)hipFree(c->g_pairs); c->g_pairs = nullptr; }
+    std::vector<GPair> gp(n_pairs);
+    for (int q = 0; q < n_pairs; ++q) gp[q] = GPair{c->plan_pairs[2 * q], c->plan_pairs[2 * q + 1]};
+    RMX_HIP(c, hipMalloc((void**)&c->g_pairs, sizeof(GPair) * (size_t)n_pairs));
+    RMX_HIP(c, hipMemcpy(c->g_pairs, gp.data(), sizeof(GPair) * (size_t)n_pairs, hipMemcpyHostToDevice));
+    c->g_pairs_n = n_pairs;
+    c->g_pairs_plan = c->plan_pairs;
+    return RMX_OK;
+}
+
+static int generic_batch(rmx_ctx* c, const void* d_iq, int n_windows, int n_pairs, int* d_lag, float* d_frac,
+                         float* d_peak, bool u8) {
+    using namespace gen;
+    int rc = generic_ensure(c, n_pairs);
+    if (rc) return rc;
+    const int N = c->n_samples, logL = c->g_logL, B = c->n_buoys;
+    const long L = 1L << logL;
+    const int hs = logL / 2;
+    const float fwd_scale = std::ldexp(1.0f, -hs), out_scale = std::ldexp(1.0f, -(logL - 2 * hs));
+    hipStream_t st = c->stream;
+    for (int w0 = 0; w0 < n_windows; w0 += c->g_chunk) {
+        const int wc = n_windows - w0 < c->g_chunk ? n_windows - w0 : c->g_chunk;
+        const int items = wc * B, slots = wc * n_pairs;
+        const long first_item = (long)w0 * B;
+        if (L <= 8192) {
+            if (u8)
+                hipLaunchKernelGGL(g_fwd_small<true>, dim3(items), dim3(kGThreads), (size_t)L * 8, st, d_iq, c->g_spec,
+                                   c->g_tw, N, logL, first_item, fwd_scale);
+            else
+                hipLaunchKernelGGL(g_fwd_small<false>, dim3(items), dim3(kGThreads), (size_t)L * 8, st, d_iq, c->g_spec,
+                                   c->g_tw, N, logL, first_item, fwd_scale);
+            hipLaunchKernelGGL(g_pair_small, dim3(slots), dim3(kGThreads), (size_t)L * 8 + kGThreads * 8, st, c->g_spec,
+                               c->g_tw, c->g_pairs, n_pairs, B, N, logL, (long)w0, out_scale, d_lag, d_frac, d_peak);
+            RMX_HIP(c, hipGetLastError());
+            continue;
+        }
+        const int l1 = c->g_logL1, l2 = c->g_logL2, L1 = 1 << l1, L2 = 1 << l2;
+        const dim3 tb(32, 8);
+        // forward: T (fused into the load), rows(L1) * W_L^(n2 k1), T, rows(L2)
+        if (u8)
+            hipLaunchKernelGGL(g_load_transposed<true>, dim3(L2 / 32, L1 / 32, items), tb, 0, st, d_iq, c->g_tmp, N, L1, L2,
+                               first_item);
+        else
+            hipLaunchKernelGGL(g_load_transposed<false>, dim3(L2 / 32, L1 / 32, items), tb, 0, st, d_iq, c->g_tmp, N, L1, L2,
+                               first_item);
+        hipLaunchKernelGGL((g_rows<true, true>), dim3(items * L2), dim3(kGThreads), (size_t)L1 * 8, st, c->g_tmp, c->g_tw1,
+                           l1, L2, l2, L, c->g_lo_bits, c->g_thi, c->g_tlo, 1.0f);
+        hipLaunchKernelGGL(g_transpose, dim3(L1 / 32, L2 / 32, items), tb, 0, st, c->g_tmp, c->g_spec, L2, L1);
+        hipLaunchKernelGGL((g_rows<true, false>), dim3(items * L1), dim3(kGThreads), (size_t)L2 * 8, st, c->g_spec,
+                           c->g_tw2, l2, L1, l1, L, c->g_lo_bits, c->g_thi, c->g_tlo, fwd_scale);
+        // pairs: product, rows(L2)^-1 * conj W_L^(n2 k1), T, rows(L1)^-1, T
+        hipLaunchKernelGGL(g_product, dim3(256, slots), dim3(256), 0, st, c->g_spec, c->g_prod, c->g_pairs, n_pairs, B, L);
+        hipLaunchKernelGGL((g_rows<false, true>), dim3(slots * L1), dim3(kGThreads), (size_t)L2 * 8, st, c->g_prod,
+                           c->g_tw2, l2, L1, l1, L, c->g_lo_bits, c->g_thi, c->g_tlo, 1.0f);
+        hipLaunchKernelGGL(g_transpose, dim3(L2 / 32, L1 / 32, slots), tb, 0, st, c->g_prod, c->g_tmp, L1, L2);
+        hipLaunchKernelGGL((g_rows<false, false>), dim3(slots * L2), dim3(kGThreads), (size_t)L1 * 8, st, c->g_tmp,
+                           c->g_tw1, l1, L2, l2, L, c->g_lo_bits, c->g_thi, c->g_tlo, 1.0f);
+        hipLaunchKernelGGL(g_transpose, dim3(L1 / 32, L2 / 32, slots), tb, 0, st, c->g_tmp, c->g_prod, L2, L1);
+        hipLaunchKernelGGL(g_absmax, dim3(64, slots), dim3(kGThreads), 0, st, c->g_prod, N, c->g_pv, c->g_pk);
+        hipLaunchKernelGGL(g_final, dim3((slots + 63) / 64), dim3(64), 0, st, c->g_prod, N, c->g_pv, c->g_pk, 64, slots,
+                           (long)w0 * n_pairs, out_scale, d_lag, d_frac, d_peak);
+        RMX_HIP(c, hipGetLastError());
+    }
+    return RMX_OK;
+}
+
+}  // namespace rmx
+
 using namespace rmx;
 
 extern "C" {
@@ -1007,9 +1163,6 @@ int rmx_create(rmx_ctx** out, int device_id, int n_buoys, int n_samples, int max
     if (!is_pow2(n_samples) || n_samples < 16 || n_samples > (1 << 22))
         return fail(nullptr, RMX_E_INVAL, "n_samples %d must be a power of two in 16..4194304", n_samples);
     if (max_windows < 1) return fail(nullptr, RMX_E_INVAL, "max_windows %d < 1", max_windows);
-    if (n_samples != kM)
-        return fail(nullptr, RMX_E_UNSUPPORTED, "n_samples %d: this build has the LDS-resident path for %d only",
-                    n_samples, kM);
     int ndev = rmx_device_count();
     if (ndev <= 0) return fail(nullptr, RMX_E_NODEV, "no HIP device visible");
     if (device_id < 0 || device_id >= ndev) return fail(nullptr, RMX_E_INVAL, "device_id %d not in 0..%d", device_id, ndev - 1);
@@ -1029,6 +1182,7 @@ int rmx_create(rmx_ctx** out, int device_id, int n_buoys, int n_samples, int max
         RMX_HIP(c, hipSetDevice(device_id));
         RMX_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         c->own_stream = true;
+        if (n_samples != kM) return rmx::generic_init(c);
         const char* env = getenv("RMX_CHUNK_WINDOWS");
         int chunk = env ? atoi(env) : 4096;
         if (chunk < 8) chunk = 8;
@@ -1069,6 +1223,9 @@ void rmx_destroy(rmx_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+    for (void* p : {(void*)c->g_tw, (void*)c->g_tw1, (void*)c->g_tw2, (void*)c->g_thi, (void*)c->g_tlo, (void*)c->g_spec,
+                    (void*)c->g_tmp, (void*)c->g_prod, (void*)c->g_pv, (void*)c->g_pk, (void*)c->g_pairs})
+        if (p) (void)hipFree(p);
     if (c->d_spec) (void)hipFree(c->d_spec);
     if (c->d_tw1) (void)hipFree(c->d_tw1);
     if (c->d_tw2) (void)hipFree(c->d_tw2);
@@ -1095,6 +1252,7 @@ int rmx_set_stream(rmx_ctx* c, void* hip_stream) {
 int rmx_set_option(rmx_ctx* c, const char* key, long value) {
     if (!c || !key) return RMX_E_INVAL;
     if (!strcmp(key, "chunk_windows")) {
+        if (c->generic) return RMX_OK;   // the generic path sizes its own chunks
         long chunk = value < 8 ? 8 : value;
         chunk = (chunk + 7) & ~7L;
         if (chunk > c->max_windows) chunk = c->max_windows;
@@ -1187,6 +1345,17 @@ int rmx_xcorr_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pa
         d_lag = c->d_lag; d_frac = c->d_frac; d_peak = c->d_peak;
     }
 
+    if (c->generic) {
+        rc = rmx::generic_batch(c, d_iq, n_windows, n_pairs, d_lag, d_frac, d_peak, u8);
+        if (rc != RMX_OK) return rc;
+        if (!out_dev) {
+            RMX_HIP(c, hipMemcpyAsync(lag_int, d_lag, out_elems * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            RMX_HIP(c, hipMemcpyAsync(lag_frac, d_frac, out_elems * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+            RMX_HIP(c, hipMemcpyAsync(peak, d_peak, out_elems * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+            RMX_HIP(c, hipStreamSynchronize(c->stream));
+        }
+        return RMX_OK;
+    }
     // power-of-two scaling: spectra carry 2^-hs, the product 2^-2hs, the taps the remaining factor
     int logl = 0;
     while ((1 << logl) < kL) ++logl;
