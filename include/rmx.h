@@ -93,6 +93,19 @@ int rmx_set_option(rmx_ctx* ctx, const char* key, long value);
 int rmx_xcorr_batch(rmx_ctx* ctx, const void* iq, int n_windows, const int32_t* pairs, int n_pairs,
                     int32_t* lag_int, float* lag_frac, float* peak, unsigned flags);
 
+/* Cross-ambiguity variant of the hot path (BASELINE configs[4]): for
+ * every window and pair (i, j) the later buoy's window is de-rotated by each Doppler hypothesis,
+ *     c_d = correlate(x[w][j] * exp(-2*pi*i*doppler_cps[d]*n), x[w][i], 'full', 'fft'),
+ * and the peak is searched over (d, lag) in d-major order (ties -> lowest d, then lowest lag index);
+ * the lag is interpolated along the lag axis of the winning row exactly as in rmx_xcorr_batch.
+ *   doppler_cps  host array [n_dopplers], cycles per sample (f_d / fs)
+ *   dop_idx      int32 [n_windows][n_pairs]  index of the winning hypothesis
+ * Same buffer/flag conventions as rmx_xcorr_batch.  The reference has no counterpart (its TDoA is a
+ * timestamp subtraction, tdoa_processor.py:166); the oracle is oracle/xcorr_ref.py:caf_pair. */
+int rmx_caf_batch(rmx_ctx* ctx, const void* iq, int n_windows, const int32_t* pairs, int n_pairs,
+                  const double* doppler_cps, int n_dopplers, int32_t* dop_idx, int32_t* lag_int,
+                  float* lag_frac, float* peak, unsigned flags);
+
 /* Wait for all work queued on the ctx stream. */
 int rmx_synchronize(rmx_ctx* ctx);
 

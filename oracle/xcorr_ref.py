@@ -167,6 +167,43 @@ def xcorr_batch_fast(iq: np.ndarray, pairs: np.ndarray | None = None, workers: i
     return lag_int, lag_frac, peak
 
 
+def doppler_phasor(nu_cps: float, n_samples: int) -> np.ndarray:
+    """exp(-2j*pi*nu*n), n = 0..N-1, evaluated in float64 and rounded once to complex64 (S8)."""
+    return np.exp(-2j * np.pi * float(nu_cps) * np.arange(n_samples)).astype(np.complex64)
+
+
+def caf_pair(x_i: np.ndarray, x_j: np.ndarray, doppler_cps):
+    """S8 (cross-ambiguity over a Doppler grid; a build choice):
+    r_d = correlate(x_j * exp(-2j*pi*nu_d*n), x_i); 2-D argmax over (d, lag) in d-major order (ties ->
+    lowest d, then lowest lag index); lag interpolated along the lag axis of the winning row.
+    Returns (doppler_idx, lag_int, lag_frac, peak)."""
+    n = x_i.shape[-1]
+    best = None
+    for d, nu in enumerate(doppler_cps):
+        y = (np.ascontiguousarray(x_j, np.complex64) * doppler_phasor(nu, n)).astype(np.complex64)
+        li, lf, pk = xcorr_pair(x_i, y)
+        if best is None or pk > best[3]:
+            best = (d, li, lf, pk)
+    return best
+
+
+def caf_batch(iq: np.ndarray, doppler_cps, pairs: np.ndarray | None = None):
+    iq = np.asarray(iq)
+    W, B, N = iq.shape
+    if pairs is None:
+        pairs = pair_list(B)
+    P = pairs.shape[0]
+    dop = np.zeros((W, P), np.int32)
+    lag_int = np.zeros((W, P), np.int32)
+    lag_frac = np.zeros((W, P), np.float64)
+    peak = np.zeros((W, P), np.float32)
+    for w in range(W):
+        for q in range(P):
+            i, j = int(pairs[q, 0]), int(pairs[q, 1])
+            dop[w, q], lag_int[w, q], lag_frac[w, q], peak[w, q] = caf_pair(iq[w, i], iq[w, j], doppler_cps)
+    return dop, lag_int, lag_frac, peak
+
+
 def peak_margin(x_i: np.ndarray, x_j: np.ndarray) -> float:
     """Relative gap between the largest and the second largest magnitude sample: the integer
     argmax is only meaningfully 'bit-exact' between two float32 FFTs when this is >> 1e-6."""

@@ -840,6 +840,43 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
 
 __global__ __launch_bounds__(kThreads, 4) void k_pair_str(RMX_PAIR_ARGS) { pair_body<false>(RMX_PAIR_PASS); }
 
+
+// ---- CAF helpers --------------------------------------------------------------------------------
+// aug[w][b] = x[w][b], aug[w][B + b] = x[w][b] * rot[n]   (rot = exp(-2 pi i nu_d n) as complex64)
+template <bool U8>
+__global__ void k_caf_augment(const void* __restrict__ iq, const float2* __restrict__ rot, float2* __restrict__ aug,
+                              int n_buoys, int n_samples) {
+#pragma clang fp contract(off)   // products and sums rounded one by one (and identically for both input types)
+    const long item = blockIdx.y;                       // w * B + b
+    const long w = item / n_buoys, b = item % n_buoys;
+    float2* o0 = aug + ((w * 2 * n_buoys) + b) * n_samples;
+    float2* o1 = aug + ((w * 2 * n_buoys) + n_buoys + b) * n_samples;
+    for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < n_samples; n += gridDim.x * blockDim.x) {
+        float2 v;
+        if constexpr (U8) {
+            const uchar2 q = reinterpret_cast<const uchar2*>(iq)[item * n_samples + n];
+            v = make_float2((float)q.x - 127.5f, (float)q.y - 127.5f);
+        } else {
+            v = reinterpret_cast<const float2*>(iq)[item * n_samples + n];
+        }
+        const float2 r = rot[n];
+        o0[n] = v;
+        // separately rounded products, as numpy multiplies complex64 (no contraction)
+        const float re = v.x * r.x - v.y * r.y;
+        const float im = v.x * r.y + v.y * r.x;
+        o1[n] = make_float2(re, im);
+    }
+}
+__global__ void k_caf_select(int d, int n, const int* __restrict__ lag_d, const float* __restrict__ frac_d,
+                             const float* __restrict__ peak_d, int* __restrict__ dop, int* __restrict__ lag,
+                             float* __restrict__ frac, float* __restrict__ peak) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (d == 0 || peak_d[i] > peak[i]) {   // strict: ties keep the lowest d
+        dop[i] = d; lag[i] = lag_d[i]; frac[i] = frac_d[i]; peak[i] = peak_d[i];
+    }
+}
+
 // ================================================================================================
 // host side
 // ================================================================================================
@@ -878,6 +915,13 @@ struct rmx_ctx {
     long g_slots_alloc = 0;
     int g_pairs_n = -1;
     std::vector<int32_t> g_pairs_plan;
+    // CAF (rmx_caf_batch): child engine over the 2B-buoy augmented windows + work buffers
+    rmx_ctx* caf_child = nullptr;
+    float2* caf_aug = nullptr;  size_t caf_aug_bytes = 0;
+    float2* caf_rot = nullptr;  size_t caf_rot_elems = 0;
+    int* caf_lag = nullptr;  float* caf_frac = nullptr;  float* caf_peak = nullptr;  int* caf_dop = nullptr;
+    size_t caf_out_elems = 0;
+    std::vector<double> caf_grid;
     // cached pair plan
     std::vector<int32_t> plan_pairs;
     int plan_n_pairs = -1, plan_n_parts = 0, plan_ppb = 0;
@@ -1226,6 +1270,10 @@ void rmx_destroy(rmx_ctx* c) {
     for (void* p : {(void*)c->g_tw, (void*)c->g_tw1, (void*)c->g_tw2, (void*)c->g_thi, (void*)c->g_tlo, (void*)c->g_spec,
                     (void*)c->g_tmp, (void*)c->g_prod, (void*)c->g_pv, (void*)c->g_pk, (void*)c->g_pairs})
         if (p) (void)hipFree(p);
+    if (c->caf_child) rmx_destroy(c->caf_child);
+    for (void* p : {(void*)c->caf_aug, (void*)c->caf_rot, (void*)c->caf_lag, (void*)c->caf_frac, (void*)c->caf_peak,
+                    (void*)c->caf_dop})
+        if (p) (void)hipFree(p);
     if (c->d_spec) (void)hipFree(c->d_spec);
     if (c->d_tw1) (void)hipFree(c->d_tw1);
     if (c->d_tw2) (void)hipFree(c->d_tw2);
@@ -1246,6 +1294,7 @@ int rmx_set_stream(rmx_ctx* c, void* hip_stream) {
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     c->stream = (hipStream_t)hip_stream;
     c->own_stream = false;
+    if (c->caf_child) return rmx_set_stream(c->caf_child, hip_stream);
     return RMX_OK;
 }
 
@@ -1427,6 +1476,128 @@ int rmx_xcorr_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pa
         RMX_HIP(c, hipMemcpyAsync(lag_int, d_lag, out_elems * sizeof(int), hipMemcpyDeviceToHost, c->stream));
         RMX_HIP(c, hipMemcpyAsync(lag_frac, d_frac, out_elems * sizeof(float), hipMemcpyDeviceToHost, c->stream));
         RMX_HIP(c, hipMemcpyAsync(peak, d_peak, out_elems * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        RMX_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    return RMX_OK;
+}
+
+int rmx_caf_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pairs, int n_pairs,
+                  const double* doppler_cps, int n_dopplers, int32_t* dop_idx, int32_t* lag_int, float* lag_frac,
+                  float* peak, unsigned flags) {
+    if (!c) return RMX_E_INVAL;
+    if (!iq || !dop_idx || !lag_int || !lag_frac || !peak || !doppler_cps) return fail(c, RMX_E_INVAL, "NULL buffer");
+    if (n_dopplers < 1 || n_dopplers > 4096) return fail(c, RMX_E_INVAL, "n_dopplers %d not in 1..4096", n_dopplers);
+    if (n_windows < 0 || n_windows > c->max_windows)
+        return fail(c, RMX_E_INVAL, "n_windows %d not in 0..max_windows=%d", n_windows, c->max_windows);
+    const int B = c->n_buoys, N = c->n_samples;
+    const int all_pairs = B * (B - 1) / 2;
+    std::vector<int32_t> pl;
+    if (!pairs) {
+        if (n_pairs != 0 && n_pairs != all_pairs)
+            return fail(c, RMX_E_INVAL, "pairs == NULL needs n_pairs == 0 or %d, got %d", all_pairs, n_pairs);
+        n_pairs = all_pairs;
+        for (int i = 0; i < B; ++i)
+            for (int j = i + 1; j < B; ++j) { pl.push_back(i); pl.push_back(B + j); }
+    } else {
+        for (int q = 0; q < n_pairs; ++q) {
+            const int i = pairs[2 * q], j = pairs[2 * q + 1];
+            if (i < 0 || j < 0 || i >= B || j >= B) return fail(c, RMX_E_INVAL, "pair %d out of range", q);
+            pl.push_back(i);
+            pl.push_back(B + j);
+        }
+    }
+    if (n_windows == 0 || n_pairs == 0) return RMX_OK;
+    RMX_HIP(c, hipSetDevice(c->device));
+    if (!c->caf_child) {
+        int rc = rmx_create(&c->caf_child, c->device, 2 * B, N, c->max_windows, 0);
+        if (rc != RMX_OK) return fail(c, rc, "CAF child engine: %s", rmx_last_error(nullptr));
+        rc = rmx_set_stream(c->caf_child, (void*)c->stream);
+        if (rc != RMX_OK) return fail(c, rc, "CAF child stream");
+    }
+    const bool in_dev = flags & RMX_IN_DEVICE, out_dev = flags & RMX_OUT_DEVICE, u8 = flags & RMX_IN_U8;
+    const size_t in_bytes = (size_t)n_windows * B * N * (u8 ? 2 : 8);
+    const void* d_iq = iq;
+    if (!in_dev) {
+        if (c->d_in_bytes < in_bytes) {
+            if (c->d_in) (void)hipFree(c->d_in);
+            c->d_in = nullptr; c->d_in_bytes = 0;
+            RMX_HIP(c, hipMalloc(&c->d_in, in_bytes));
+            c->d_in_bytes = in_bytes;
+        }
+        RMX_HIP(c, hipMemcpyAsync(c->d_in, iq, in_bytes, hipMemcpyHostToDevice, c->stream));
+        d_iq = c->d_in;
+    }
+    const size_t aug_bytes = (size_t)n_windows * 2 * B * N * sizeof(float2);
+    if (c->caf_aug_bytes < aug_bytes) {
+        if (c->caf_aug) (void)hipFree(c->caf_aug);
+        c->caf_aug = nullptr; c->caf_aug_bytes = 0;
+        RMX_HIP(c, hipMalloc((void**)&c->caf_aug, aug_bytes));
+        c->caf_aug_bytes = aug_bytes;
+    }
+    // phasor table [D][N]: exp(-2 pi i nu n) in double, rounded once to float
+    std::vector<double> grid(doppler_cps, doppler_cps + n_dopplers);
+    if (grid != c->caf_grid || c->caf_rot_elems < (size_t)n_dopplers * N) {
+        std::vector<float2> rot((size_t)n_dopplers * N);
+        for (int d = 0; d < n_dopplers; ++d)
+            for (int n = 0; n < N; ++n) {
+                const double a = -6.283185307179586476925286766559 * grid[d] * (double)n;
+                rot[(size_t)d * N + n] = make_float2((float)std::cos(a), (float)std::sin(a));
+            }
+        if (c->caf_rot) (void)hipFree(c->caf_rot);
+        c->caf_rot = nullptr; c->caf_rot_elems = 0;
+        RMX_HIP(c, hipMalloc((void**)&c->caf_rot, rot.size() * sizeof(float2)));
+        RMX_HIP(c, hipMemcpy(c->caf_rot, rot.data(), rot.size() * sizeof(float2), hipMemcpyHostToDevice));
+        c->caf_rot_elems = rot.size();
+        c->caf_grid = grid;
+    }
+    const size_t out_elems = (size_t)n_windows * n_pairs;
+    if (c->caf_out_elems < out_elems) {
+        for (void* p : {(void*)c->caf_lag, (void*)c->caf_frac, (void*)c->caf_peak, (void*)c->caf_dop})
+            if (p) (void)hipFree(p);
+        c->caf_lag = nullptr; c->caf_frac = nullptr; c->caf_peak = nullptr; c->caf_dop = nullptr; c->caf_out_elems = 0;
+        RMX_HIP(c, hipMalloc((void**)&c->caf_lag, out_elems * sizeof(int)));
+        RMX_HIP(c, hipMalloc((void**)&c->caf_frac, out_elems * sizeof(float)));
+        RMX_HIP(c, hipMalloc((void**)&c->caf_peak, out_elems * sizeof(float)));
+        RMX_HIP(c, hipMalloc((void**)&c->caf_dop, out_elems * sizeof(int)));
+        c->caf_out_elems = out_elems;
+    }
+    int *b_dop = dop_idx, *b_lag = lag_int;
+    float *b_frac = lag_frac, *b_peak = peak;
+    if (!out_dev) {
+        if (c->d_out_elems < out_elems) {
+            if (c->d_lag) (void)hipFree(c->d_lag);
+            if (c->d_frac) (void)hipFree(c->d_frac);
+            if (c->d_peak) (void)hipFree(c->d_peak);
+            c->d_lag = nullptr; c->d_frac = nullptr; c->d_peak = nullptr; c->d_out_elems = 0;
+            RMX_HIP(c, hipMalloc((void**)&c->d_lag, out_elems * sizeof(int)));
+            RMX_HIP(c, hipMalloc((void**)&c->d_frac, out_elems * sizeof(float)));
+            RMX_HIP(c, hipMalloc((void**)&c->d_peak, out_elems * sizeof(float)));
+            c->d_out_elems = out_elems;
+        }
+        b_dop = c->caf_dop; b_lag = c->d_lag; b_frac = c->d_frac; b_peak = c->d_peak;
+    }
+    const int items = n_windows * B;
+    for (int d = 0; d < n_dopplers; ++d) {
+        const dim3 grid_aug((N + 255) / 256 > 64 ? 64 : (N + 255) / 256, items);
+        if (u8)
+            hipLaunchKernelGGL(k_caf_augment<true>, grid_aug, dim3(256), 0, c->stream, d_iq, c->caf_rot + (size_t)d * N,
+                               c->caf_aug, B, N);
+        else
+            hipLaunchKernelGGL(k_caf_augment<false>, grid_aug, dim3(256), 0, c->stream, d_iq, c->caf_rot + (size_t)d * N,
+                               c->caf_aug, B, N);
+        RMX_HIP(c, hipGetLastError());
+        const int rc = rmx_xcorr_batch(c->caf_child, c->caf_aug, n_windows, pl.data(), n_pairs, c->caf_lag, c->caf_frac,
+                                       c->caf_peak, RMX_IN_DEVICE | RMX_OUT_DEVICE);
+        if (rc != RMX_OK) return fail(c, rc, "CAF bin %d: %s", d, rmx_last_error(c->caf_child));
+        hipLaunchKernelGGL(k_caf_select, dim3((unsigned)((out_elems + 255) / 256)), dim3(256), 0, c->stream, d,
+                           (int)out_elems, c->caf_lag, c->caf_frac, c->caf_peak, b_dop, b_lag, b_frac, b_peak);
+        RMX_HIP(c, hipGetLastError());
+    }
+    if (!out_dev) {
+        RMX_HIP(c, hipMemcpyAsync(dop_idx, b_dop, out_elems * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        RMX_HIP(c, hipMemcpyAsync(lag_int, b_lag, out_elems * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        RMX_HIP(c, hipMemcpyAsync(lag_frac, b_frac, out_elems * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        RMX_HIP(c, hipMemcpyAsync(peak, b_peak, out_elems * sizeof(float), hipMemcpyDeviceToHost, c->stream));
         RMX_HIP(c, hipStreamSynchronize(c->stream));
     }
     return RMX_OK;

@@ -31,11 +31,13 @@ def _next_pow2(n: int) -> int:
 def make_windows(n_windows: int, n_buoys: int, n_samples: int, sample_rate_hz: float,
                  seed: int, snr_db: float = 10.0, bandwidth: float = 0.8,
                  rms: float = 32.0, quantise: bool = True, max_delay: float | None = None,
-                 return_u8: bool = False):
+                 return_u8: bool = False, doppler_cps: np.ndarray | None = None):
     """Returns (iq complex64 [W][B][N], delays float64 [W][B]) and, with return_u8, also the raw
     interleaved uint8 [W][B][2N] that decodes (u8 - 127.5) to exactly ``iq``.
 
     True lag of pair (i, j) is delays[:, j] - delays[:, i] (buoy2 - buoy1, tdoa_processor.py:51).
+    doppler_cps: optional [W][B] (or [B]) frequency offsets in cycles/sample applied per buoy as
+    exp(+2j*pi*nu*n) after the delay (SURVEY.md section 8a-spec S8 / BASELINE cfg5).
     """
     rng = np.random.default_rng(seed)
     W, B, N = n_windows, n_buoys, n_samples
@@ -59,6 +61,9 @@ def make_windows(n_windows: int, n_buoys: int, n_samples: int, sample_rate_hz: f
         S *= np.sqrt(Ns / (2.0 * mask.sum())) * np.sqrt(Ns)
         ramp = np.exp(-2j * np.pi * freqs[None, None, :] * delays[w0:w1, :, None])
         s = np.fft.ifft(S[:, None, :] * ramp, axis=-1)[:, :, margin:margin + N]
+        if doppler_cps is not None:
+            nu = np.broadcast_to(np.asarray(doppler_cps, np.float64), (W, B))[w0:w1]
+            s = s * np.exp(2j * np.pi * nu[:, :, None] * np.arange(N)[None, None, :])
         noise = (rng.standard_normal((c, B, N)) + 1j * rng.standard_normal((c, B, N))) \
             * (noise_amp / np.sqrt(2.0))
         x = (s * sig_amp + noise) * scale

@@ -63,6 +63,8 @@ def load_library():
     lib.rmx_set_option.restype = ci
     lib.rmx_xcorr_batch.argtypes = [vp, vp, ci, vp, ci, vp, vp, vp, cu]
     lib.rmx_xcorr_batch.restype = ci
+    lib.rmx_caf_batch.argtypes = [vp, vp, ci, vp, ci, vp, ci, vp, vp, vp, vp, cu]
+    lib.rmx_caf_batch.restype = ci
     lib.rmx_synchronize.argtypes = [vp]
     lib.rmx_synchronize.restype = ci
     lib.rmx_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(ci), C.POINTER(C.c_float),
@@ -75,7 +77,7 @@ def load_library():
 
 
 EXPORTS = ["rmx_version", "rmx_device_count", "rmx_create", "rmx_destroy", "rmx_last_error",
-           "rmx_set_stream", "rmx_set_option", "rmx_xcorr_batch", "rmx_synchronize",
+           "rmx_set_stream", "rmx_set_option", "rmx_xcorr_batch", "rmx_caf_batch", "rmx_synchronize",
            "rmx_last_timing", "rmx_scratch_bytes"]
 
 
@@ -178,6 +180,38 @@ class XcorrEngine:
             lag_int.ctypes.data_as(C.c_void_p), lag_frac.ctypes.data_as(C.c_void_p),
             peak.ctypes.data_as(C.c_void_p), flags))
         return lag_int, lag_frac, peak
+
+    def caf(self, iq: np.ndarray, doppler_cps, pairs: Optional[np.ndarray] = None):
+        """Cross-ambiguity search (rmx_caf_batch): host arrays in and out.  doppler_cps: hypotheses in
+        cycles/sample.  Returns (doppler_idx int32, lag_int int32, lag_frac float32, peak float32),
+        each [W][P]."""
+        iq = np.asarray(iq)
+        flags = 0
+        if iq.dtype == np.uint8:
+            flags |= RMX_IN_U8
+        else:
+            iq = np.ascontiguousarray(iq, dtype=np.complex64)
+        iq = np.ascontiguousarray(iq)
+        W = iq.shape[0]
+        if pairs is not None:
+            pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+            P = pairs.shape[0]
+            pp = pairs.ctypes.data_as(C.c_void_p)
+        else:
+            P = self.n_buoys * (self.n_buoys - 1) // 2
+            pp = None
+        dc = np.ascontiguousarray(doppler_cps, dtype=np.float64)
+        dop = np.zeros((W, P), np.int32)
+        lag_int = np.zeros((W, P), np.int32)
+        lag_frac = np.zeros((W, P), np.float32)
+        peak = np.zeros((W, P), np.float32)
+        if W == 0 or P == 0:
+            return dop, lag_int, lag_frac, peak
+        self._check(self._lib.rmx_caf_batch(
+            self._ctx, iq.ctypes.data_as(C.c_void_p), W, pp, P, dc.ctypes.data_as(C.c_void_p), dc.shape[0],
+            dop.ctypes.data_as(C.c_void_p), lag_int.ctypes.data_as(C.c_void_p),
+            lag_frac.ctypes.data_as(C.c_void_p), peak.ctypes.data_as(C.c_void_p), flags))
+        return dop, lag_int, lag_frac, peak
 
     def correlate_device(self, iq_ptr: int, n_windows: int, lag_int_ptr: int, lag_frac_ptr: int,
                          peak_ptr: int, pairs: Optional[np.ndarray] = None, u8: bool = False):

@@ -13,6 +13,8 @@ It imports ``/root/reference/tdoa_processor.py`` and records
   order (``tdoa_processor.py:156-157``), reduced by the path's spec (SURVEY.md §8a-spec S4-S6:
   ``np.abs`` -> ``np.argmax`` -> 3-point parabola).  Small cases store their inputs (as the raw
   uint8 I/Q that decodes to them); large cases store the generator seed + an input checksum.
+* ``caf_*.npz`` -- the same primitive over a Doppler grid (``run_caf_case``); ``--caf-only``
+  regenerates just these.
 * ``tdoa_conventions.json`` -- ``TDoACalculator.calculate_tdoa_measurements`` on the hand-built
   detections of the reference's own ``main()`` example (``tdoa_processor.py:475-490``): pins the
   pair order, the sign (buoy2 - buoy1) and the ns -> metres conversion.
@@ -78,12 +80,61 @@ def run_case(ref, iq):
                 margin=margin, taps=taps)
 
 
+def run_caf_case(ref, iq, doppler_cps):
+    """Cross-ambiguity fixture: per pair and Doppler hypothesis d the
+    reference primitive is called on the de-rotated later window,
+    ``correlate((x_j * exp(-2j*pi*nu_d*n)).astype(complex64), x_i, 'full', 'fft')``; the winning
+    (d, lag) is the d-major first maximum of |c|."""
+    W, B, N = iq.shape
+    pairs = [(i, j) for i in range(B) for j in range(i + 1, B)]
+    P, D = len(pairs), len(doppler_cps)
+    n = np.arange(N)
+    rot = [np.exp(-2j * np.pi * nu * n).astype(np.complex64) for nu in doppler_cps]
+    out = dict(pairs=np.array(pairs, np.int32), doppler_cps=np.asarray(doppler_cps, np.float64),
+               dop_idx=np.zeros((W, P), np.int32), lag_int=np.zeros((W, P), np.int32),
+               lag_frac=np.zeros((W, P), np.float64), peak=np.zeros((W, P), np.float32),
+               bin_peak=np.zeros((W, P, D), np.float32), bin_lag=np.zeros((W, P, D), np.int32))
+    for w in range(W):
+        for q, (i, j) in enumerate(pairs):
+            best = None
+            for d in range(D):
+                y = (iq[w, j] * rot[d]).astype(np.complex64)
+                c = ref.correlate(y, iq[w, i], mode="full", method="fft")
+                li, fr, pk, _, _ = reduce_full(c, N)
+                out["bin_peak"][w, q, d] = pk
+                out["bin_lag"][w, q, d] = li
+                if best is None or np.float32(pk) > np.float32(best[3]):
+                    best = (d, li, fr, pk)
+            out["dop_idx"][w, q], out["lag_int"][w, q], out["lag_frac"][w, q], out["peak"][w, q] = best
+    return out
+
+
+def make_caf(ref):
+    cases = [
+        ("caf_b3_n4096", dict(n_windows=2, n_buoys=3, n_samples=4096, sample_rate_hz=2.4e6, seed=21), 9, 0.5,
+         [0, 1, -2]),
+        ("caf_b3_n1024", dict(n_windows=2, n_buoys=3, n_samples=1024, sample_rate_hz=2.4e6, seed=22), 7, 0.5,
+         [1, -1, 2]),
+    ]
+    for name, kw, nd, step_bins, offs in cases:
+        step = step_bins / kw["n_samples"]                     # cycles/sample
+        grid = (np.arange(nd) - nd // 2) * step
+        iq, delays, raw = rm.synth.make_windows(return_u8=True, doppler_cps=np.array(offs) * step, **kw)
+        res = run_caf_case(ref, iq, grid)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), raw_u8=raw, delays=delays,
+                            buoy_doppler_cps=np.array(offs) * step, sample_rate_hz=kw["sample_rate_hz"], **res)
+        print(name, "dop", res["dop_idx"].tolist(), "lag", res["lag_int"].tolist())
+
+
 def checksum(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
 def main():
     ref = load_reference()
+    if "--caf-only" in sys.argv:
+        make_caf(ref)
+        return
     import scipy
     meta = dict(numpy=np.__version__, scipy=scipy.__version__,
                 primitive="tdoa_processor.correlate(x_j, x_i, mode='full', method='fft')")
@@ -119,6 +170,8 @@ def main():
     res = run_case(ref, e)
     np.savez_compressed(os.path.join(HERE, "xcorr_edge_n256.npz"), iq=e, **res)
     print("edge lags", res["lag_int"].ravel(), res["lag_frac"].ravel())
+
+    make_caf(ref)
 
     # large, seed-regenerated cases (inputs not stored)
     large = [

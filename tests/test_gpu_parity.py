@@ -227,3 +227,30 @@ def test_tdoa_processor_with_iq(xc):
         ns, metres = orc.lag_to_tdoa(oi[0, q] + of_[0, q], fs)
         assert abs(m.time_difference_ns - ns) <= 1
         assert abs(m.distance_difference_m - m.time_difference_ns / 1e9 * 299792458.0) < 1e-9
+
+
+@pytest.mark.parametrize("name", ["caf_b3_n4096", "caf_b3_n1024"])
+def test_caf_golden(xc, golden_dir, name):
+    """rmx_caf_batch against the Doppler-grid fixtures generated with the reference primitive:
+    winning hypothesis and integer lag exact, fractional lag / peak to 1e-5; per-bin peaks of the
+    fixture give the margin between the best and the second-best hypothesis (>= 1e-2 here)."""
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    iq = orc.decode_u8_iq(g["raw_u8"])
+    W, B, N = iq.shape
+    bp = np.sort(g["bin_peak"].astype(np.float64), axis=-1)
+    assert ((bp[..., -1] - bp[..., -2]) / bp[..., -1]).min() > 1e-3
+    with xc.XcorrEngine(B, N, W) as eng:
+        dop, li, lf, pk = eng.caf(iq, g["doppler_cps"])
+        assert np.array_equal(dop, g["dop_idx"])
+        _assert_parity(li, lf, pk, g["lag_int"], g["lag_frac"], g["peak"])
+        dop8, li8, lf8, pk8 = eng.caf(g["raw_u8"], g["doppler_cps"])
+        assert np.array_equal(dop, dop8) and np.array_equal(li, li8) and np.array_equal(lf, lf8)
+        # a single zero-Doppler hypothesis is the plain path
+        d0, l0, f0, p0 = eng.caf(iq, [0.0])
+        l1, f1, p1 = eng.correlate(iq)
+        assert not d0.any() and np.array_equal(l0, l1)
+        assert np.allclose(l0 + f0, l1 + f1, atol=TOL) and np.allclose(p0, p1, rtol=1e-5)
+        # custom pair list
+        sel = np.array([[1, 2], [0, 2]], np.int32)
+        ds, ls, fs_, ps = eng.caf(iq, g["doppler_cps"], sel)
+        assert np.array_equal(ds, dop[:, [2, 1]]) and np.array_equal(ls, li[:, [2, 1]])

@@ -91,3 +91,19 @@ def test_decode_u8_matches_reference_decode():
     raw = np.arange(256, dtype=np.uint8)
     z = orc.decode_u8_iq(raw)
     assert z.dtype == np.complex64 and z[0] == np.complex64(-127.5 - 126.5j) and z[-1] == np.complex64(126.5 + 127.5j)
+
+
+@pytest.mark.parametrize("name", ["caf_b3_n4096", "caf_b3_n1024"])
+def test_caf_oracle_matches_reference_outputs(golden_dir, name):
+    """Cross-ambiguity (S8): the oracle's per-bin call is the reference primitive on the de-rotated
+    window, so the reduction over (d, lag) is bit-identical to the fixture."""
+    g = _load(golden_dir, name)
+    iq = orc.decode_u8_iq(g["raw_u8"])
+    dop, li, lf, pk = orc.caf_batch(iq, g["doppler_cps"])
+    assert np.array_equal(dop, g["dop_idx"]) and np.array_equal(li, g["lag_int"])
+    assert np.array_equal(lf, g["lag_frac"]) and np.array_equal(pk, g["peak"])
+    # the winning hypothesis is the relative Doppler the generator applied
+    rel = g["buoy_doppler_cps"][g["pairs"][:, 1]] - g["buoy_doppler_cps"][g["pairs"][:, 0]]
+    assert np.allclose(g["doppler_cps"][dop], np.broadcast_to(rel, dop.shape), atol=1e-12)
+    true = g["delays"][:, g["pairs"][:, 1]] - g["delays"][:, g["pairs"][:, 0]]
+    assert np.all(np.abs(li + lf - true) < 0.5)
