@@ -18,6 +18,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 namespace rmx {
 
 constexpr int kM = 4096;       // sub-transform length (= window length N of the LDS path)
@@ -124,6 +126,38 @@ __device__ __forceinline__ void dft16_layer2(float2 (&v)[16]) {
     swap2(v[11], v[14]);
 }
 
+// The same layer, handing each group's four outputs X[ka], X[ka+4], X[ka+8], X[ka+12] to `emit` as soon
+// as they exist (ka as an integral_constant), with a scheduling fence after each group: the caller's
+// LDS stores and global prefetch requests are then spread over the layer's arithmetic instead of
+// hitting the LDS store path / the texture-address queue in one burst at its end (all eight waves
+// of the workgroup run in barrier-aligned lockstep, so a burst is eight bursts at once).  v is left
+// in layer order (not un-transposed).
+template <class F>
+__device__ __forceinline__ void dft16_layer2_emit(float2 (&v)[16], F&& emit) {
+    dft4(v[0], v[1], v[2], v[3]);                                                  // ka = 0
+    emit(std::integral_constant<int, 0>{}, v[0], v[1], v[2], v[3]);
+    __builtin_amdgcn_sched_barrier(0);
+    dft4_tw<true>(v[4], v[5], v[6], v[7], make_float2(1.f, 0.f), make_float2(RMX_C1, -RMX_S1),
+                  make_float2(RMX_RH, -RMX_RH), make_float2(RMX_S1, -RMX_C1));      // ka = 1
+    emit(std::integral_constant<int, 1>{}, v[4], v[5], v[6], v[7]);
+    __builtin_amdgcn_sched_barrier(0);
+    {                                                                              // ka = 2
+        float2 &a0 = v[8], &a1 = v[9], &a2 = v[10], &a3 = v[11];
+        const float2 t0 = make_float2(a0.x + a2.y, a0.y - a2.x);
+        const float2 t1 = make_float2(a0.x - a2.y, a0.y + a2.x);
+        const float2 A1 = make_float2((a1.x + a1.y) * RMX_RH, (a1.y - a1.x) * RMX_RH);
+        const float2 t2 = cfma(A1, a3, make_float2(-RMX_RH, -RMX_RH));
+        const float2 t3 = twice_minus(A1, t2);
+        dft4_tail(a0, a1, a2, a3, t0, t1, t2, t3);
+    }
+    emit(std::integral_constant<int, 2>{}, v[8], v[9], v[10], v[11]);
+    __builtin_amdgcn_sched_barrier(0);
+    dft4_tw<true>(v[12], v[13], v[14], v[15], make_float2(1.f, 0.f), make_float2(RMX_S1, -RMX_C1),
+                  make_float2(-RMX_RH, -RMX_RH), make_float2(-RMX_C1, RMX_S1));    // ka = 3
+    emit(std::integral_constant<int, 3>{}, v[12], v[13], v[14], v[15]);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // 16-point DFT, X[k] = sum_q v[q] W16^(qk), natural order in, natural order out (150 instructions).
 __device__ __forceinline__ void dft16(float2 (&v)[16]) {
     // q = 4*q1 + q0, k = ka + 4*kb.  Layer 1: DFT4 over q1 for each q0 -> y[q0][ka] in v[q0+4ka].
@@ -155,27 +189,39 @@ struct C16 {
     __device__ __forceinline__ void set(int q, float x, float y) { re[q] = x; im[q] = y; }
 };
 template <bool W0_IS_ONE>
-__device__ __forceinline__ void dft16_tw(float2 (&v)[16], const C16& w) {
+__device__ __forceinline__ void dft16_tw_l1(float2 (&v)[16], const C16& w) {   // layer 1 only
     dft4_tw<W0_IS_ONE>(v[0], v[4], v[8], v[12], w.get(0), w.get(4), w.get(8), w.get(12));
     dft4_tw<false>(v[1], v[5], v[9], v[13], w.get(1), w.get(5), w.get(9), w.get(13));
     dft4_tw<false>(v[2], v[6], v[10], v[14], w.get(2), w.get(6), w.get(10), w.get(14));
     dft4_tw<false>(v[3], v[7], v[11], v[15], w.get(3), w.get(7), w.get(11), w.get(15));
+}
+template <bool W0_IS_ONE>
+__device__ __forceinline__ void dft16_tw(float2 (&v)[16], const C16& w) {
+    dft16_tw_l1<W0_IS_ONE>(v, w);
     dft16_layer2(v);
 }
 
-// 16-point DFT of (v[q] * tw[q]) with the twiddle row fetched just in time from LDS: `row` holds the
-// 16 twiddles in layer-1 group order, row[2*q0 + h] = (tw[q0 + 8h], tw[q0 + 4 + 8h]) as float4, so
-// each DFT4 group needs two ds_read_b128 and only ~8 twiddle registers are live at a time.
-// tw[0] must be 1 (TW2 rows).
+// 16-point DFT of (v[q] * tw[q]) with the twiddle row fetched just in time from LDS.  tw[0] is 1 (TW2
+// rows) and is not stored: `row` holds the other 15 twiddles in layer-1 group order, s = 4*q0 + m - 1
+// for tw[q0 + 4*m], packed two per float4 from a 16-byte aligned base, so the row is eight full
+// ds_read_b128 (256 B/clk; the compiler pairs a row that starts on the unused tw[0] into
+// ds_read2_b64, 128 B/clk) and only ~8 twiddle registers are live at a time.
+__device__ __forceinline__ void dft16_tw_row_l1(float2 (&v)[16], const float4* row) {   // layer 1 only
+    const float4 f0 = row[0], f1 = row[1];
+    dft4_tw<true>(v[0], v[4], v[8], v[12], make_float2(1.0f, 0.0f), make_float2(f0.x, f0.y), make_float2(f0.z, f0.w),
+                  make_float2(f1.x, f1.y));
+    const float4 f2 = row[2], f3 = row[3];
+    dft4_tw<false>(v[1], v[5], v[9], v[13], make_float2(f1.z, f1.w), make_float2(f2.x, f2.y), make_float2(f2.z, f2.w),
+                   make_float2(f3.x, f3.y));
+    const float4 f4 = row[4], f5 = row[5];
+    dft4_tw<false>(v[2], v[6], v[10], v[14], make_float2(f3.z, f3.w), make_float2(f4.x, f4.y), make_float2(f4.z, f4.w),
+                   make_float2(f5.x, f5.y));
+    const float4 f6 = row[6], f7 = row[7];
+    dft4_tw<false>(v[3], v[7], v[11], v[15], make_float2(f5.z, f5.w), make_float2(f6.x, f6.y), make_float2(f6.z, f6.w),
+                   make_float2(f7.x, f7.y));
+}
 __device__ __forceinline__ void dft16_tw_row(float2 (&v)[16], const float4* row) {
-#pragma unroll
-    for (int q0 = 0; q0 < 4; ++q0) {
-        const float4 f0 = row[2 * q0], f1 = row[2 * q0 + 1];
-        const float2 w0 = make_float2(f0.x, f0.y), w1 = make_float2(f0.z, f0.w);
-        const float2 w2 = make_float2(f1.x, f1.y), w3 = make_float2(f1.z, f1.w);
-        if (q0 == 0) dft4_tw<true>(v[0], v[4], v[8], v[12], w0, w1, w2, w3);
-        else dft4_tw<false>(v[q0], v[q0 + 4], v[q0 + 8], v[q0 + 12], w0, w1, w2, w3);
-    }
+    dft16_tw_row_l1(v, row);
     dft16_layer2(v);
 }
 
@@ -226,13 +272,24 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Same ordering without the wait: a wave's LDS instructions execute in issue order, so its reads
+// queue behind its own writes (wavefront-scope fences are compiler-only on gfx9).
+__device__ __forceinline__ void wave_lds_order() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ void xchg_a_write(float2* lds, const float2 (&v)[16], int t) {
 #pragma unroll
     for (int k0 = 0; k0 < 16; ++k0) lds[k0 * kBcHalf + t] = make_float2(v[k0].x, v[k0].y);
 }
 __device__ __forceinline__ void xchg_a_read(const float2* lds, float2 (&v)[16], int t) {
+    // issue order = layer-1 consumption order (slots q0, q0+4, q0+8, q0+12 feed the q0-th DFT4)
 #pragma unroll
-    for (int k0 = 0; k0 < 16; ++k0) v[k0] = lds[k0 * kBcHalf + t];
+    for (int q0 = 0; q0 < 4; ++q0)
+#pragma unroll
+        for (int q1 = 0; q1 < 4; ++q1) v[q0 + 4 * q1] = lds[(q0 + 4 * q1) * kBcHalf + t];
 }
 // role B thread: u = 16*k0 + n0; slot = n1
 __device__ __forceinline__ void xchg_b_write(float2* lds, const float2 (&v)[16], int t) {
@@ -274,7 +331,9 @@ __device__ __forceinline__ void xchg_bc_read_b(const float2* lds, float2 (&v)[16
     const int p = t & 1, u = t >> 1, k0 = u >> 4, a = u & 15;
     const float2* base = lds + k0 * kBcHalf + 2 * a + p;
 #pragma unroll
-    for (int k1 = 0; k1 < 16; ++k1) v[k1] = base[k1 * kBcRow];
+    for (int q0 = 0; q0 < 4; ++q0)
+#pragma unroll
+        for (int q1 = 0; q1 < 4; ++q1) v[q0 + 4 * q1] = base[(q0 + 4 * q1) * kBcRow];
 }
 
 // TW2[a][b] = W_256^(a*b) lives in LDS as 16 rows of 16 complex padded to 18 (144-B rows: the 16

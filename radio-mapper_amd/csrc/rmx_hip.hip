@@ -51,11 +51,12 @@ __device__ __forceinline__ void load_tw2_to_lds(float2* tw2_lds, const float2* _
     if (t < 256) tw2_lds[(t >> 4) * kTw2RowF2 + (t & 15)] = tw2_g[t];
 }
 
-// same table in layer-1 group order for dft16_tw_row: stored[4*q0 + m] = tw2[a][q0 + 4*m]
+// same table in layer-1 group order for dft16_tw_row: stored[4*q0 + m - 1] = tw2[a][q0 + 4*m]; the
+// unused tw2[a][0] = 1 goes to the pad slot 15
 __device__ __forceinline__ void load_tw2_to_lds_grouped(float2* tw2_lds, const float2* __restrict__ tw2_g, int t) {
     if (t < 256) {
         const int a = t >> 4, q = t & 15;
-        tw2_lds[a * kTw2RowF2 + 4 * (q & 3) + (q >> 2)] = tw2_g[t];
+        tw2_lds[a * kTw2RowF2 + (q == 0 ? 15 : 4 * (q & 3) + (q >> 2) - 1)] = tw2_g[t];
     }
 }
 
@@ -502,9 +503,13 @@ __global__ __launch_bounds__(kThreads, 2) void k_pair_res(
 // in another wave.  The pair's winner is resolved by one lane after the NEXT pair's barrier.
 constexpr int kLdsWinImg = kLdsXchg;                                 // 69632 each, two of them
 constexpr int kLdsWinTw2 = 2 * kLdsWinImg;
-constexpr int kLdsWinHalo = kLdsWinTw2 + kLdsTw2;                     // [2][8][4][16] float
-constexpr int kLdsWinRed = kLdsWinHalo + 2 * 8 * 4 * 16 * 4;          // [2][8] float4
-constexpr int kLdsWinBytes = kLdsWinRed + 2 * 8 * 16;
+constexpr int kResSlots = 8;   // record ring; winners are resolved in batches of kResBatch pairs
+constexpr int kResBatch = 7;   // < kResSlots: the pair after a batch writes a slot the resolver is not reading
+constexpr int kLdsWinHalo = kLdsWinTw2 + kLdsTw2;                           // [slots][8][4][16] float
+constexpr int kLdsWinRed = kLdsWinHalo + kResSlots * 8 * 4 * 16 * 4;        // [slots][8] float4
+constexpr int kLdsWinOidx = kLdsWinRed + kResSlots * 8 * 16;                // [slots] int: output slot of the pair
+constexpr int kLdsWinBytes = kLdsWinOidx + kResSlots * 4;
+static_assert(kLdsWinBytes <= 160 * 1024, "k_win LDS");
 
 __device__ __forceinline__ void k_to_owner(int kk, int& tt, int& q) {
     const int par = (kk >= kM - 1) ? 0 : 1;
@@ -513,27 +518,35 @@ __device__ __forceinline__ void k_to_owner(int kk, int& tt, int& q) {
     q = n >> 8;
 }
 
-// Executed by ONE whole wave after the barrier that published the records (wave-uniform call):
-// lanes 0..7 fetch the 8 wave records, two DPP reductions pick (max |r|^2, lowest 'full' index), the
-// neighbour taps come from the winner's record or from the halo rows; lane 0 stores the 12 bytes.
-__device__ __forceinline__ void resolve_win(int lane, const float4* red, const float* halo, long out_pos,
-                                            float out_scale, int* __restrict__ lag_int,
-                                            float* __restrict__ lag_frac, float* __restrict__ peak) {
-    // record w = {max |r|^2, its lowest 'full' index (int bits), tap k*-1, tap k*+1}; scalar LDS reads
-    // (a float4 struct read back as int would live in scratch, and every scratch access costs a
-    // vmcnt wait that drains the spectra requested a pair ahead)
-    const float* rf = reinterpret_cast<const float*>(red) + 4 * (lane & 7);
+// Executed by ONE whole wave after a barrier that published the records of `cnt` <= 7 pairs (ring
+// slots first, first+1, ...): lane = 8*g + r looks at wave r's record of the g-th pair, two DPP
+// reductions over each group of 8 lanes pick (max |r|^2, lowest 'full' index), the neighbour taps
+// come from the winner's own record or from the halo rows, and the winning lane of every group
+// stores the pair's 12 bytes.  One resolve per 7 pairs instead of one per pair: the resolving wave
+// is late to its next barrier by the length of this routine, and the other seven wait for it.
+__device__ __forceinline__ void resolve_batch(int lane, const float4* red, const float* halo, const int* oidx,
+                                              int first, int cnt, long obase, float out_scale,
+                                              int* __restrict__ lag_int, float* __restrict__ lag_frac,
+                                              float* __restrict__ peak) {
+    const int g = lane >> 3, r = lane & 7;
+    const bool act = g < cnt;
+    const int slot = (first + g) & (kResSlots - 1);
+    // record = {max |r|^2, its lowest 'full' index (int bits), tap k*-1, tap k*+1}; scalar LDS reads
+    const float* rf = reinterpret_cast<const float*>(red) + 4 * (slot * 8 + r);
     const int* ri = reinterpret_cast<const int*>(rf);
-    const bool act = lane < 8;
     const float ex = act ? rf[0] : -3.0f;
     const int k = act ? ri[1] : 0x7fffffff;
-    const float ez = act ? rf[2] : -2.0f, ew = act ? rf[3] : -2.0f;
-    const float gmax = wave_max_f32(ex);
-    const int kstar = wave_min_i32(ex == gmax ? k : 0x7fffffff);
-    const unsigned long long win = __ballot(ex == gmax && k == kstar);
-    const int wlane = __builtin_ctzll(win);
-    const float tm = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ez), wlane));
-    const float tp = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ew), wlane));
+    const float tm = rf[2], tp = rf[3];
+    const int out = oidx[slot];
+    float gmax = ex;                                     // max over the 8 lanes of the group
+    gmax = fmaxf(gmax, __builtin_bit_cast(float, dpp_i<0xB1>(__builtin_bit_cast(int, gmax))));
+    gmax = fmaxf(gmax, __builtin_bit_cast(float, dpp_i<0x4E>(__builtin_bit_cast(int, gmax))));
+    gmax = fmaxf(gmax, __builtin_bit_cast(float, dpp_i<0x141>(__builtin_bit_cast(int, gmax))));
+    int kstar = (ex == gmax) ? k : 0x7fffffff;
+    kstar = min(kstar, dpp_i<0xB1>(kstar));
+    kstar = min(kstar, dpp_i<0x4E>(kstar));
+    kstar = min(kstar, dpp_i<0x141>(kstar));
+    const bool win = act && ex == gmax && k == kstar;     // exactly one lane per active group
     // halo rows (always read, clamped): only lanes 0,1,62,63 of a wave can own a cross-wave neighbour
     auto halo_tap = [&](int kk) -> float {
         kk = kk < 0 ? 0 : (kk > 2 * kM - 2 ? 2 * kM - 2 : kk);
@@ -541,21 +554,35 @@ __device__ __forceinline__ void resolve_win(int lane, const float4* red, const f
         k_to_owner(kk, tt, q);
         const int ln = tt & 63;
         const int row = ln < 2 ? ln : (ln >= 62 ? ln - 60 : 0);
-        return halo[(((tt >> 6) * 4) + row) * 16 + q];
+        return halo[(((slot * 8 + (tt >> 6)) * 4) + row) * 16 + q];
     };
-    const float hm = halo_tap(kstar - 1), hp = halo_tap(kstar + 1);
-    const float b = sqrtf(gmax) * out_scale;
+    const int kc = win ? k : (kM - 1);
+    const float hm = halo_tap(kc - 1), hp = halo_tap(kc + 1);
+    const float b = sqrtf(fmaxf(ex, 0.0f)) * out_scale;
     const float a = sqrtf(tm >= 0.0f ? tm : hm) * out_scale;
     const float c = sqrtf(tp >= 0.0f ? tp : hp) * out_scale;
     const double den = (double)a - 2.0 * (double)b + (double)c;
     float frac = 0.0f;
-    if (kstar > 0 && kstar < 2 * kM - 2 && den != 0.0) frac = (float)(0.5 * ((double)a - (double)c) / den);
-    if (lane == 0) {
-        lag_int[out_pos] = kstar - (kM - 1);
-        lag_frac[out_pos] = frac;
-        peak[out_pos] = b;
+    if (kc > 0 && kc < 2 * kM - 2 && den != 0.0) frac = (float)(0.5 * ((double)a - (double)c) / den);
+    if (win) {
+        lag_int[obase + out] = kc - (kM - 1);
+        lag_frac[obase + out] = frac;
+        peak[obase + out] = b;
     }
 }
+
+#ifdef RMX_PROF
+// per-phase cycle accounting of the pair lambda (s_memtime stamps; wave 0 of two chosen workgroups)
+__device__ unsigned long long g_prof[2][16];
+#define RMX_STAMP(i)                                      \
+    do {                                                  \
+        __builtin_amdgcn_sched_barrier(0);                \
+        stamp[i] = __builtin_amdgcn_s_memtime();          \
+        __builtin_amdgcn_sched_barrier(0);                \
+    } while (0)
+#else
+#define RMX_STAMP(i) do { } while (0)
+#endif
 
 // Schedule of one window (all pairs i<j of B buoys; the anchor spectrum X_i is resident in registers,
 // X_j streams one pair ahead):
@@ -584,6 +611,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
     float2* tw2_lds = reinterpret_cast<float2*>(smem + kLdsWinTw2);
     float* halo = reinterpret_cast<float*>(smem + kLdsWinHalo);
     float4* red = reinterpret_cast<float4*>(smem + kLdsWinRed);
+    int* oidx = reinterpret_cast<int*>(smem + kLdsWinOidx);
 
     const int t = threadIdx.x;
     const int p = t & 1, u = t >> 1;
@@ -605,17 +633,22 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
     __syncthreads();
 
     int seq = 0;         // transform counter: selects the exchange image
-    int npair = 0;       // pair counter: selects the record buffer
-    int pending = -1;    // output slot of the pair whose records await the next barrier
+    int npair = 0;       // pair counter: selects the record slot (ring of kResSlots)
+    int npend = 0;       // pairs whose records await a resolve
 
     C16 sa, sb;   // anchor spectrum X_i and the streamed X_j (scalar arrays: see C16)
+#ifdef RMX_PROF
+    unsigned long long prof_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
 
-    auto barrier_hook = [&]() __attribute__((always_inline)) {
+    auto barrier_hook = [&](bool flush) __attribute__((always_inline)) {
         if (!(dbg & 1)) __syncthreads();
-        if (!(dbg & 2) && pending >= 0 && wave == (seq & 7))
-            resolve_win(lane, red + ((npair - 1) & 1) * 8, halo + ((npair - 1) & 1) * (8 * 4 * 16), obase + pending,
-                        out_scale, lag_int, lag_frac, peak);
-        pending = -1;
+        if (npend == kResBatch || (flush && npend > 0)) {
+            if (!(dbg & 2) && wave == (seq & 7))
+                resolve_batch(lane, red, halo, oidx, (npair - npend) & (kResSlots - 1), npend, obase, out_scale, lag_int,
+                              lag_frac, peak);
+            npend = 0;
+        }
     };
     // odd lanes: v[q] *= W32^q, the per-slot part of the odd sub-transform's W_L^n (in place)
     auto mul_w32_odd = [&](float2 (&v)[16]) __attribute__((always_inline)) {
@@ -654,6 +687,21 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
             }
         }
     };
+    // quarter G of the same loads (slots 4G..4G+3): issued between the groups of a butterfly layer
+    auto load_x_part = [&](C16& d, int b, auto part) __attribute__((always_inline)) {
+        constexpr int G = decltype(part)::value;
+        if constexpr (U8) {
+#pragma unroll
+            for (int q = 4 * G; q < 4 * G + 4; ++q)
+                d.re[q] = __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b16(xs, xoff, (b * kM + q * 256) * 2, 0));
+        } else {
+#pragma unroll
+            for (int q = 4 * G; q < 4 * G + 4; ++q) {
+                const u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(xs, xoff, (b * kM + q * 256) * 8, 0);
+                d.set(q, __uint_as_float(r.x), __uint_as_float(r.y));
+            }
+        }
+    };
     auto cvt_x = [&](C16& d) __attribute__((always_inline)) {
         if constexpr (U8) {
 #pragma unroll
@@ -666,6 +714,15 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
     auto load_spec = [&](C16& d, int b) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
+            const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(ss, soff, (b * 8 + j) * (kThreads * 16), 0);
+            d.set(2 * j, __uint_as_float(w.x), __uint_as_float(w.y));
+            d.set(2 * j + 1, __uint_as_float(w.z), __uint_as_float(w.w));
+        }
+    };
+    auto load_spec_part = [&](C16& d, int b, auto part) __attribute__((always_inline)) {
+        constexpr int G = decltype(part)::value;
+#pragma unroll
+        for (int j = 2 * G; j < 2 * G + 2; ++j) {
             const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(ss, soff, (b * 8 + j) * (kThreads * 16), 0);
             d.set(2 * j, __uint_as_float(w.x), __uint_as_float(w.y));
             d.set(2 * j + 1, __uint_as_float(w.z), __uint_as_float(w.w));
@@ -695,12 +752,12 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
         dft16(x);
         mul_tw1(x, tw1);
         if (!(dbg & 8)) xchg_a_write(img, x, t);
-        barrier_hook();
+        barrier_hook(false);
         if (!(dbg & 8)) xchg_b_read(img, x, t);
         dft16(x);
         if (!(dbg & 4)) {
         xchg_bc_write_b(img, x, t);
-        wave_lds_fence();
+        wave_lds_order();
         xchg_bc_read_c(img, x, t);
         }
         dft16_tw_row(x, tw2row);   // W_256^(n0*k1) as pre-twiddle of the last pass
@@ -713,29 +770,64 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
     auto pair = [&](const C16& a, const C16& s, int out_idx, auto prefetch)
                     __attribute__((always_inline)) {
         float2* img = (seq & 1) ? img1 : img0;
-        const int rb = npair & 1;
+        const int rb = npair & (kResSlots - 1);
         float2 v[16];
+#ifdef RMX_PROF
+        unsigned long long stamp[10];
+#endif
+        RMX_STAMP(0);
         // R = X_j conj(X_i), (im,re)-swapped == swap(X_j) * X_i: merged into the first radix-16 pass
 #pragma unroll
         for (int q = 0; q < 16; ++q) v[q] = make_float2(s.im[q], s.re[q]);
-        dft16_tw<false>(v, a);                   // k2 -> n0   (role C)
+        dft16_tw_l1<false>(v, a);                // k2 -> n0   (role C), layer 1: the last reads of a and s
 #pragma unroll
         for (int q = 0; q < 16; q += 4)          // pin: the requests below must follow the reads above
             asm volatile("" : "+v"(v[q].x), "+v"(v[q].y), "+v"(v[q + 1].x), "+v"(v[q + 1].y), "+v"(v[q + 2].x),
                          "+v"(v[q + 2].y), "+v"(v[q + 3].x), "+v"(v[q + 3].y));
         __builtin_amdgcn_sched_barrier(0);
-        if (!(dbg & 16)) prefetch();
-        __builtin_amdgcn_sched_barrier(0);
-        if (!(dbg & 4)) {
-        xchg_bc_write_c(img, v, t);
-        wave_lds_fence();
-        xchg_bc_read_b(img, v, t);
+        RMX_STAMP(1);
+        {   // layer 2 group by group: each group's outputs go to the wave-local image at once, and a
+            // quarter of the next spectra is requested behind it
+            float2* wb = img + (u >> 4) * kBcHalf + (u & 15) * kBcRow + p;
+            dft16_layer2_emit(v, [&](auto kac, const float2& x0, const float2& x1, const float2& x2, const float2& x3)
+                                     __attribute__((always_inline)) {
+                constexpr int ka = decltype(kac)::value;
+                if (!(dbg & 4)) {
+                    wb[2 * ka] = make_float2(x0.x, x0.y);
+                    wb[2 * (ka + 4)] = make_float2(x1.x, x1.y);
+                    wb[2 * (ka + 8)] = make_float2(x2.x, x2.y);
+                    wb[2 * (ka + 12)] = make_float2(x3.x, x3.y);
+                }
+                if (!(dbg & 16)) prefetch(kac);
+            });
         }
-        dft16_tw_row(v, tw2row);                 // W_256^(n0*k1), k1 -> n1   (role B)
-        if (!(dbg & 8)) xchg_b_write(img, v, t);                 // own half-wave regions
-        barrier_hook();                          // the pair's only barrier
+        if (!(dbg & 4)) {
+            wave_lds_order();
+            xchg_bc_read_b(img, v, t);
+        }
+        RMX_STAMP(2);
+        dft16_tw_row_l1(v, tw2row);              // W_256^(n0*k1), k1 -> n1   (role B), layer 1
+        RMX_STAMP(3);
+        {
+            float2* xb = img + (u >> 4) * kBcHalf + (u & 15) * 2 + p;   // own half-wave regions
+            dft16_layer2_emit(v, [&](auto kac, const float2& x0, const float2& x1, const float2& x2, const float2& x3)
+                                     __attribute__((always_inline)) {
+                constexpr int ka = decltype(kac)::value;
+                if (!(dbg & 8)) {
+                    xb[ka * 32] = make_float2(x0.x, x0.y);
+                    xb[(ka + 4) * 32] = make_float2(x1.x, x1.y);
+                    xb[(ka + 8) * 32] = make_float2(x2.x, x2.y);
+                    xb[(ka + 12) * 32] = make_float2(x3.x, x3.y);
+                }
+            });
+        }
+        RMX_STAMP(4);
+        barrier_hook(false);                     // the pair's only barrier
+        RMX_STAMP(5);
         if (!(dbg & 8)) xchg_a_read(img, v, t);
+        RMX_STAMP(6);
         dft16_tw<false>(v, tw1);                 // W_M^(u*k0) [* W_L^u odd], k0 -> n2   (role A)
+        RMX_STAMP(7);
         mul_w32_odd(v);                          // odd lanes: * W32^q
         // last radix-2 stage across the lane pair, up to a sign that |.| does not see:
         // even lane e + o' = r[n], odd lane o' - e = -r[n+M]
@@ -747,12 +839,13 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
 #pragma unroll
         for (int q = 0; q < 16; ++q) mag[q] = fmaf(v[q].x, v[q].x, v[q].y * v[q].y);
         if (p && u == 0) mag[0] = -1.0f;         // lag -M is not part of the 'full' output
+        RMX_STAMP(8);
         if (dbg & 2) {
             float s = 0;
 #pragma unroll
             for (int q = 0; q < 16; ++q) s += mag[q];
             if (s == 12345.678f) lag_int[0] = 1;
-            pending = out_idx; ++seq; ++npair;
+            ++npend; ++seq; ++npair;
             return;
         }
         if (is_halo) {
@@ -783,8 +876,17 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
         if (lane == 0) {
             const u32x4 rec = {__float_as_uint(wmax), (unsigned)kw, __float_as_uint(tapm), __float_as_uint(tapp)};
             *reinterpret_cast<u32x4*>(red + rb * 8 + wave) = rec;
+            if (wave == 0) oidx[rb] = out_idx;
         }
-        pending = out_idx;
+        RMX_STAMP(9);
+#ifdef RMX_PROF
+        if (npair >= 7) {   // phase-2 pairs only
+#pragma unroll
+            for (int i = 0; i < 9; ++i) prof_acc[i] += stamp[i + 1] - stamp[i];
+            prof_acc[9] += 1;
+        }
+#endif
+        ++npend;
         ++seq;
         ++npair;
     };
@@ -800,12 +902,12 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
         cvt_x(sb);
         fwd(sb);
         store_spec(sb, e);
-        pair(sa, sb, out_of(0, e), [&]() __attribute__((always_inline)) {
+        pair(sa, sb, out_of(0, e), [&](auto part) __attribute__((always_inline)) {
             if (e + 1 < B) {
-                load_x(sb, e + 1);
+                load_x_part(sb, e + 1, part);
             } else if (B > 2) {        // next anchor 1 streams downwards from B-1: X_{B-1} is L2-hot
-                load_spec(sa, 1);
-                load_spec(sb, B - 1);
+                load_spec_part(sa, 1, part);
+                load_spec_part(sb, B - 1, part);
             }
         });
     }
@@ -815,18 +917,24 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
         const int n = B - 1 - i;                 // pairs of this anchor
         for (int s = 0; s < n; ++s) {
             const int j = (i & 1) ? (B - 1 - s) : (i + 1 + s);
-            pair(sa, sb, out_of(i, j), [&]() __attribute__((always_inline)) {
+            pair(sa, sb, out_of(i, j), [&](auto part) __attribute__((always_inline)) {
                 if (s + 1 < n) {
-                    load_spec(sb, (i & 1) ? (j - 1) : (j + 1));
+                    load_spec_part(sb, (i & 1) ? (j - 1) : (j + 1), part);
                 } else if (i + 2 < B) {
-                    load_spec(sa, i + 1);
-                    load_spec(sb, ((i + 1) & 1) ? (B - 1) : (i + 2));
+                    load_spec_part(sa, i + 1, part);
+                    load_spec_part(sb, ((i + 1) & 1) ? (B - 1) : (i + 2), part);
                 }
             });
         }
     }
-    seq = 0;   // any wave may resolve the last pair; take wave 0
-    barrier_hook();
+    seq = 0;   // any wave may resolve the last pairs; take wave 0
+    barrier_hook(true);
+#ifdef RMX_PROF
+    if (wl == 300 && (t == 0 || t == 448)) {   // waves 0 and 7 of one workgroup
+#pragma unroll
+        for (int i = 0; i < 10; ++i) g_prof[t != 0][i] = prof_acc[i];
+    }
+#endif
 }
 
 #define RMX_PAIR_ARGS                                                                                         \
@@ -1602,6 +1710,12 @@ int rmx_caf_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pair
     }
     return RMX_OK;
 }
+
+#ifdef RMX_PROF
+extern "C" int rmx_debug_read_prof(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(rmx::g_prof), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : -3;
+}
+#endif
 
 int rmx_synchronize(rmx_ctx* c) {
     if (!c) return RMX_E_INVAL;
