@@ -690,6 +690,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
     // quarter G of the same loads (slots 4G..4G+3): issued between the groups of a butterfly layer
     auto load_x_part = [&](C16& d, int b, auto part) __attribute__((always_inline)) {
         constexpr int G = decltype(part)::value;
+        if (dbg & 64) return;   // ablation: no window-sample requests
         if constexpr (U8) {
 #pragma unroll
             for (int q = 4 * G; q < 4 * G + 4; ++q)
@@ -721,6 +722,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
     };
     auto load_spec_part = [&](C16& d, int b, auto part) __attribute__((always_inline)) {
         constexpr int G = decltype(part)::value;
+        if (dbg & 32) b = 1;   // ablation: every request hits the same (cache-resident) spectrum
+        if (dbg & 128) return;  // ablation: no spectrum requests
 #pragma unroll
         for (int j = 2 * G; j < 2 * G + 2; ++j) {
             const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(ss, soff, (b * 8 + j) * (kThreads * 16), 0);
@@ -765,17 +768,17 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
         for (int q = 0; q < 16; ++q) xc.set(q, x[q].x * fwd_scale, x[q].y * fwd_scale);
         ++seq;
     };
-    // one pair: anchor a (conjugated side, buoy i), stream s (buoy j); `prefetch` runs after the last
-    // read of a and s (their registers may be reloaded there, a whole pair ahead of their next use)
-    auto pair = [&](const C16& a, const C16& s, int out_idx, auto prefetch)
-                    __attribute__((always_inline)) {
-        float2* img = (seq & 1) ? img1 : img0;
-        const int rb = npair & (kResSlots - 1);
+    // One pair = two halves around its only workgroup barrier.
+    //   h1  conj-multiply merged into the role-C pass, wave-local exchange, role-B pass, stores into
+    //       exchange image `tr & 1` (this wave's own regions); `prefetch(part)` is called four times
+    //       after the last read of a and s (their registers may be reloaded there)
+    //   h2  reads image `tr & 1` (all waves' regions), role-A pass, last radix-2, |.|^2, peak records
+    // h2 of pair n and h1 of pair n+1 sit between the same two barriers and do not depend on each
+    // other (different images, disjoint registers), so the two waves that share a SIMD can run them in
+    // opposite order: see the phase-2 loop.
+    auto pair_h1 = [&](const C16& a, const C16& s, int tr, auto prefetch) __attribute__((always_inline)) {
+        float2* img = (tr & 1) ? img1 : img0;
         float2 v[16];
-#ifdef RMX_PROF
-        unsigned long long stamp[10];
-#endif
-        RMX_STAMP(0);
         // R = X_j conj(X_i), (im,re)-swapped == swap(X_j) * X_i: merged into the first radix-16 pass
 #pragma unroll
         for (int q = 0; q < 16; ++q) v[q] = make_float2(s.im[q], s.re[q]);
@@ -785,7 +788,6 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
             asm volatile("" : "+v"(v[q].x), "+v"(v[q].y), "+v"(v[q + 1].x), "+v"(v[q + 1].y), "+v"(v[q + 2].x),
                          "+v"(v[q + 2].y), "+v"(v[q + 3].x), "+v"(v[q + 3].y));
         __builtin_amdgcn_sched_barrier(0);
-        RMX_STAMP(1);
         {   // layer 2 group by group: each group's outputs go to the wave-local image at once, and a
             // quarter of the next spectra is requested behind it
             float2* wb = img + (u >> 4) * kBcHalf + (u & 15) * kBcRow + p;
@@ -805,9 +807,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
             wave_lds_order();
             xchg_bc_read_b(img, v, t);
         }
-        RMX_STAMP(2);
         dft16_tw_row_l1(v, tw2row);              // W_256^(n0*k1), k1 -> n1   (role B), layer 1
-        RMX_STAMP(3);
         {
             float2* xb = img + (u >> 4) * kBcHalf + (u & 15) * 2 + p;   // own half-wave regions
             dft16_layer2_emit(v, [&](auto kac, const float2& x0, const float2& x1, const float2& x2, const float2& x3)
@@ -821,13 +821,13 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
                 }
             });
         }
-        RMX_STAMP(4);
-        barrier_hook(false);                     // the pair's only barrier
-        RMX_STAMP(5);
+    };
+    auto pair_h2 = [&](int tr, int out_idx) __attribute__((always_inline)) {
+        const float2* img = (tr & 1) ? img1 : img0;
+        const int rb = npair & (kResSlots - 1);
+        float2 v[16];
         if (!(dbg & 8)) xchg_a_read(img, v, t);
-        RMX_STAMP(6);
         dft16_tw<false>(v, tw1);                 // W_M^(u*k0) [* W_L^u odd], k0 -> n2   (role A)
-        RMX_STAMP(7);
         mul_w32_odd(v);                          // odd lanes: * W32^q
         // last radix-2 stage across the lane pair, up to a sign that |.| does not see:
         // even lane e + o' = r[n], odd lane o' - e = -r[n+M]
@@ -839,13 +839,12 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
 #pragma unroll
         for (int q = 0; q < 16; ++q) mag[q] = fmaf(v[q].x, v[q].x, v[q].y * v[q].y);
         if (p && u == 0) mag[0] = -1.0f;         // lag -M is not part of the 'full' output
-        RMX_STAMP(8);
         if (dbg & 2) {
             float s = 0;
 #pragma unroll
             for (int q = 0; q < 16; ++q) s += mag[q];
             if (s == 12345.678f) lag_int[0] = 1;
-            ++npend; ++seq; ++npair;
+            ++npend; ++npair;
             return;
         }
         if (is_halo) {
@@ -859,7 +858,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
         for (int q = 1; q < 16; ++q) tmax = fmaxf(tmax, mag[q]);
         int qsel = 16;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) qsel = min(qsel, mag[q] == tmax ? q : 16);   // lowest slot holding the max
+        for (int q = 15; q >= 0; --q) qsel = (mag[q] == tmax) ? q : qsel;   // lowest slot holding the max
         const int kq = kbase + qsel * 256;
         const float wmax = wave_max_f32(tmax);
         const int kw = wave_min_i32(tmax == wmax ? kq : 0x7fffffff);
@@ -878,53 +877,104 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
             *reinterpret_cast<u32x4*>(red + rb * 8 + wave) = rec;
             if (wave == 0) oidx[rb] = out_idx;
         }
-        RMX_STAMP(9);
-#ifdef RMX_PROF
-        if (npair >= 7) {   // phase-2 pairs only
-#pragma unroll
-            for (int i = 0; i < 9; ++i) prof_acc[i] += stamp[i + 1] - stamp[i];
-            prof_acc[9] += 1;
-        }
-#endif
         ++npend;
-        ++seq;
         ++npair;
+    };
+    auto pair = [&](const C16& a, const C16& s, int out_idx, auto prefetch) __attribute__((always_inline)) {
+        pair_h1(a, s, seq, prefetch);
+        barrier_hook(false);                     // the pair's only barrier
+        pair_h2(seq, out_idx);
+        ++seq;
     };
     auto out_of = [&](int i, int j) -> int { return i * B - (i * (i + 1)) / 2 + (j - i - 1); };
 
     // ---- anchor 0: X_0 goes straight into the anchor registers (never stored); every other X_e is
     // transformed once, stored once for the later anchors, and used at once from registers for (0,e)
+    // The window samples come cold from HBM (the spectra, by contrast, are re-read out of the
+    // Infinity Cache): a request issued in the first half of pair (0,e) and used at the start of the
+    // next forward transform has ~2.4 us to arrive, which is not enough.  A third register buffer xn
+    // (live in this phase only) doubles the distance: X_{e+2}'s samples are requested into xn while
+    // pair (0,e) runs, and move from xn to sb one pair later.
+    C16 xn;
+    auto copy_x_part = [&](C16& d, const C16& s, auto part) __attribute__((always_inline)) {
+        constexpr int G = decltype(part)::value;
+#pragma unroll
+        for (int q = 4 * G; q < 4 * G + 4; ++q) {
+            d.re[q] = s.re[q];
+            if constexpr (!U8) d.im[q] = s.im[q];
+        }
+    };
     load_x(sa, 0);
+    if (B > 1) load_x(sb, 1);          // sb and xn are free: these travel while X_0 is transformed
+    if (B > 2) load_x(xn, 2);
     cvt_x(sa);
     fwd(sa);
-    if (B > 1) load_x(sb, 1);
-    for (int e = 1; e < B; ++e) {
+    // (the last buoy is peeled off the loop: its pair requests spectra instead of samples; with both
+    // request kinds in one loop body the compiler's waitcnt bookkeeping merges their destination
+    // registers across the back edge)
+    for (int e = 1; e + 1 < B; ++e) {
         cvt_x(sb);
         fwd(sb);
         store_spec(sb, e);
         pair(sa, sb, out_of(0, e), [&](auto part) __attribute__((always_inline)) {
-            if (e + 1 < B) {
-                load_x_part(sb, e + 1, part);
-            } else if (B > 2) {        // next anchor 1 streams downwards from B-1: X_{B-1} is L2-hot
+            copy_x_part(sb, xn, part);                       // X_{e+1}'s samples, requested a pair ago
+            if (e + 2 < B) load_x_part(xn, e + 2, part);
+        });
+    }
+    if (B > 1) {
+        cvt_x(sb);
+        fwd(sb);
+        store_spec(sb, B - 1);
+        pair(sa, sb, out_of(0, B - 1), [&](auto part) __attribute__((always_inline)) {
+            if (B > 2) {               // next anchor 1 streams downwards from B-1: X_{B-1} is L2-hot
                 load_spec_part(sa, 1, part);
                 load_spec_part(sb, B - 1, part);
             }
         });
     }
     // ---- anchors 1..B-2: the stream direction alternates (odd anchors walk j down, even ones up), so
-    // the first spectra an anchor streams are the ones the previous anchor touched last (L2 hits)
-    for (int i = 1; i + 1 < B; ++i) {
-        const int n = B - 1 - i;                 // pairs of this anchor
-        for (int s = 0; s < n; ++s) {
-            const int j = (i & 1) ? (B - 1 - s) : (i + 1 + s);
-            pair(sa, sb, out_of(i, j), [&](auto part) __attribute__((always_inline)) {
-                if (s + 1 < n) {
-                    load_spec_part(sb, (i & 1) ? (j - 1) : (j + 1), part);
-                } else if (i + 2 < B) {
-                    load_spec_part(sa, i + 1, part);
-                    load_spec_part(sb, ((i + 1) & 1) ? (B - 1) : (i + 2), part);
+    // the first spectra an anchor streams are the ones the previous anchor touched last (L2 hits).
+    // Between two barriers sit h2 of pair m and h1 of pair m+1, which are independent: waves 0-3 run
+    // them in that order and waves 4-7 (the second wave of each SIMD) in the opposite order, so that
+    // one wave's LDS / barrier / DPP-chain stalls fall on the other's butterfly arithmetic instead of
+    // on the same stalls (all eight waves are otherwise barrier-aligned in lockstep).
+    {
+        const int M2 = (B - 1) * (B - 2) / 2;            // pairs of this phase
+        const bool late_h2 = (wave >> 1) & 1;   // SIMD pairs {a, a+2} vs {a+1, a+3}: measured best of the three splits
+        auto j_of = [&](int i, int s) -> int { return (i & 1) ? (B - 1 - s) : (i + 1 + s); };
+        int ci = 1, cs = 0;                              // pair m     (anchor, position in its run)
+        int ni = 1, ns = 1;                              // pair m + 1
+        if (ns >= B - 1 - ni) { ++ni; ns = 0; }
+        auto h1_of = [&](int hi, int hs, int tr) __attribute__((always_inline)) {
+            // spectra for the pair after (hi, hs) are requested here
+            int pi = hi, ps = hs + 1;
+            if (ps >= B - 1 - pi) { ++pi; ps = 0; }
+            const bool valid = pi + 1 < B;
+            const bool new_anchor = pi != hi;
+            const int pj = j_of(pi, ps);
+            pair_h1(sa, sb, tr, [&](auto part) __attribute__((always_inline)) {
+                if (valid) {
+                    if (new_anchor) load_spec_part(sa, pi, part);
+                    load_spec_part(sb, pj, part);
                 }
             });
+        };
+        if (M2 > 0) h1_of(ci, cs, seq);
+        for (int m = 0; m < M2; ++m) {
+            barrier_hook(false);
+            const bool has_next = m + 1 < M2;
+            const int out_idx = out_of(ci, j_of(ci, cs));
+            if (late_h2) {
+                if (has_next) h1_of(ni, ns, seq + 1);
+                pair_h2(seq, out_idx);
+            } else {
+                pair_h2(seq, out_idx);
+                if (has_next) h1_of(ni, ns, seq + 1);
+            }
+            ++seq;
+            ci = ni; cs = ns;
+            ++ns;
+            if (ns >= B - 1 - ni) { ++ni; ns = 0; }
         }
     }
     seq = 0;   // any wave may resolve the last pairs; take wave 0
