@@ -571,19 +571,6 @@ __device__ __forceinline__ void resolve_batch(int lane, const float4* red, const
     }
 }
 
-#ifdef RMX_PROF
-// per-phase cycle accounting of the pair lambda (s_memtime stamps; wave 0 of two chosen workgroups)
-__device__ unsigned long long g_prof[2][16];
-#define RMX_STAMP(i)                                      \
-    do {                                                  \
-        __builtin_amdgcn_sched_barrier(0);                \
-        stamp[i] = __builtin_amdgcn_s_memtime();          \
-        __builtin_amdgcn_sched_barrier(0);                \
-    } while (0)
-#else
-#define RMX_STAMP(i) do { } while (0)
-#endif
-
 // Schedule of one window (all pairs i<j of B buoys; the anchor spectrum X_i is resident in registers,
 // X_j streams one pair ahead):
 //   anchor 0      X_0 is transformed straight into the anchor registers (never stored); every further
@@ -598,7 +585,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
                                                      const float2* __restrict__ tw2_g, int n_buoys,
                                                      long first_window, float fwd_scale, float out_scale,
                                                      int* __restrict__ lag_int, float* __restrict__ lag_frac,
-                                                     float* __restrict__ peak, int dbg_rt) {
+                                                     float* __restrict__ peak, int n_win, int dbg_rt) {
 #ifdef RMX_ABLATE
     const int dbg = dbg_rt;   // timing-only ablation build (wrong results): tools/gpu_probe.py
 #else
@@ -616,11 +603,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
     const int t = threadIdx.x;
     const int p = t & 1, u = t >> 1;
     const int lane = t & 63, wave = t >> 6;
-    const int wl = blockIdx.x;
     const int B = n_buoys;
-    const long wbase = (long)wl * B;
     const int n_pairs = B * (B - 1) / 2;
-    const long obase = (first_window + wl) * (long)n_pairs;
 
     load_tw2_to_lds_grouped(tw2_lds, tw2_g, t);
     float2 tw1[16];
@@ -632,14 +616,15 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
     const bool is_halo = lane < 2 || lane >= 62;
     __syncthreads();
 
+    // persistent workgroup: the tables above are loaded once, then windows blockIdx.x, +gridDim.x, ...
+    for (int wl = blockIdx.x; wl < n_win; wl += gridDim.x) {
+    C16 sa, sb;   // anchor spectrum X_i and the streamed X_j (scalar arrays: see C16)
+    const long wbase = (long)wl * B;
+    const long obase = (first_window + wl) * (long)n_pairs;
     int seq = 0;         // transform counter: selects the exchange image
     int npair = 0;       // pair counter: selects the record slot (ring of kResSlots)
     int npend = 0;       // pairs whose records await a resolve
 
-    C16 sa, sb;   // anchor spectrum X_i and the streamed X_j (scalar arrays: see C16)
-#ifdef RMX_PROF
-    unsigned long long prof_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#endif
 
     auto barrier_hook = [&](bool flush) __attribute__((always_inline)) {
         if (!(dbg & 1)) __syncthreads();
@@ -688,21 +673,22 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
         }
     };
     // quarter G of the same loads (slots 4G..4G+3): issued between the groups of a butterfly layer
-    auto load_x_part = [&](C16& d, int b, auto part) __attribute__((always_inline)) {
+    auto load_x_part_from = [&](const __amdgpu_buffer_rsrc_t& rs, C16& d, int b, auto part) __attribute__((always_inline)) {
         constexpr int G = decltype(part)::value;
         if (dbg & 64) return;   // ablation: no window-sample requests
         if constexpr (U8) {
 #pragma unroll
             for (int q = 4 * G; q < 4 * G + 4; ++q)
-                d.re[q] = __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b16(xs, xoff, (b * kM + q * 256) * 2, 0));
+                d.re[q] = __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs, xoff, (b * kM + q * 256) * 2, 0));
         } else {
 #pragma unroll
             for (int q = 4 * G; q < 4 * G + 4; ++q) {
-                const u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(xs, xoff, (b * kM + q * 256) * 8, 0);
+                const u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(rs, xoff, (b * kM + q * 256) * 8, 0);
                 d.set(q, __uint_as_float(r.x), __uint_as_float(r.y));
             }
         }
     };
+    auto load_x_part = [&](C16& d, int b, auto part) __attribute__((always_inline)) { load_x_part_from(xs, d, b, part); };
     auto cvt_x = [&](C16& d) __attribute__((always_inline)) {
         if constexpr (U8) {
 #pragma unroll
@@ -979,12 +965,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
     }
     seq = 0;   // any wave may resolve the last pairs; take wave 0
     barrier_hook(true);
-#ifdef RMX_PROF
-    if (wl == 300 && (t == 0 || t == 448)) {   // waves 0 and 7 of one workgroup
-#pragma unroll
-        for (int i = 0; i < 10; ++i) g_prof[t != 0][i] = prof_acc[i];
-    }
-#endif
+    }   // next window of this workgroup
 }
 
 #define RMX_PAIR_ARGS                                                                                         \
@@ -1044,6 +1025,7 @@ static thread_local std::string g_create_error;
 
 struct rmx_ctx {
     int device = 0;
+    int n_cus = 256;   // compute units of the device (persistent-grid size of the fused kernel)
     int n_buoys = 0, n_samples = 0, max_windows = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -1382,6 +1364,11 @@ int rmx_create(rmx_ctx** out, int device_id, int n_buoys, int n_samples, int max
     };
     auto init = [&]() -> int {
         RMX_HIP(c, hipSetDevice(device_id));
+        {
+            int ncu = 0;
+            if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && ncu > 0)
+                c->n_cus = ncu;
+        }
         RMX_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         c->own_stream = true;
         if (n_samples != kM) return rmx::generic_init(c);
@@ -1581,15 +1568,17 @@ int rmx_xcorr_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pa
     for (int w0 = 0; w0 < n_windows; w0 += c->chunk_windows) {
         const int wc = (n_windows - w0 < c->chunk_windows) ? n_windows - w0 : c->chunk_windows;
         if (c->fused && c->plan_all_pairs) {
+            // one persistent workgroup per CU (the kernel's LDS footprint allows exactly one)
+            const int wgrid = wc < c->n_cus ? wc : c->n_cus;
             if (c->timing) RMX_HIP(c, hipEventRecord(c->ev[c->ev_used], c->stream));
             if (u8)
-                hipLaunchKernelGGL(k_win<true>, dim3(wc), dim3(kThreads), kLdsWinBytes, c->stream, d_iq, c->d_spec,
+                hipLaunchKernelGGL(k_win<true>, dim3(wgrid), dim3(kThreads), kLdsWinBytes, c->stream, d_iq, c->d_spec,
                                    c->d_tw1, c->d_tw2, c->n_buoys, (long)w0, fwd_scale, out_scale, d_lag, d_frac,
-                                   d_peak, c->dbg);
+                                   d_peak, wc, c->dbg);
             else
-                hipLaunchKernelGGL(k_win<false>, dim3(wc), dim3(kThreads), kLdsWinBytes, c->stream, d_iq, c->d_spec,
+                hipLaunchKernelGGL(k_win<false>, dim3(wgrid), dim3(kThreads), kLdsWinBytes, c->stream, d_iq, c->d_spec,
                                    c->d_tw1, c->d_tw2, c->n_buoys, (long)w0, fwd_scale, out_scale, d_lag, d_frac,
-                                   d_peak, c->dbg);
+                                   d_peak, wc, c->dbg);
             RMX_HIP(c, hipGetLastError());
             if (c->timing) {
                 RMX_HIP(c, hipEventRecord(c->ev[c->ev_used + 1], c->stream));
@@ -1760,12 +1749,6 @@ int rmx_caf_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pair
     }
     return RMX_OK;
 }
-
-#ifdef RMX_PROF
-extern "C" int rmx_debug_read_prof(unsigned long long* out) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(rmx::g_prof), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : -3;
-}
-#endif
 
 int rmx_synchronize(rmx_ctx* c) {
     if (!c) return RMX_E_INVAL;
