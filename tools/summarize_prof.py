@@ -30,11 +30,23 @@ def main():
         keep = [rows[0]] + [r for r in rows[1:] if any(k in r[0] for k in ours)]
         with open(os.path.join(out, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
             csv.writer(f).writerows(keep)
+    # full-size launches only (bench.py's parity leg launches the same kernel on 32 windows)
+    tr = glob.glob(os.path.join(src, "stats", "*kernel_trace.csv"))
+    if tr:
+        rows = [r for r in csv.DictReader(open(tr[0])) if any(k in r["Kernel_Name"] for k in ours)]
+        if rows:
+            gmax = max(int(r["Grid_Size_X"]) for r in rows)
+            d = sorted((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in rows if int(r["Grid_Size_X"]) == gmax)
+            with open(os.path.join(out, f"{tag}_kernel_stats.csv"), "a", newline="") as f:
+                csv.writer(f).writerow([f"# full-size launches (grid {gmax}): n={len(d)} avg_ns={sum(d) / len(d):.0f} "
+                                        f"median_ns={d[len(d) // 2]} min_ns={d[0]} max_ns={d[-1]}"])
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for p in glob.glob(os.path.join(src, "pmc_*", "*counter_collection.csv")):
-        for r in csv.DictReader(open(p)):
+        rows = [r for r in csv.DictReader(open(p)) if any(k in r["Kernel_Name"] for k in ours)]
+        gmax = max([int(r["Grid_Size"]) for r in rows], default=0)
+        for r in rows:
             name = r["Kernel_Name"].split("(")[0].split("<")[0]
-            if any(k in name for k in ours):
+            if int(r["Grid_Size"]) == gmax:
                 agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
     pmc = {k: {c: sum(v) / len(v) for c, v in d.items()} | {"launches_sampled": len(next(iter(d.values())))}
            for k, d in agg.items()}
