@@ -254,3 +254,36 @@ def test_caf_golden(xc, golden_dir, name):
         sel = np.array([[1, 2], [0, 2]], np.int32)
         ds, ls, fs_, ps = eng.caf(iq, g["doppler_cps"], sel)
         assert np.array_equal(ds, dop[:, [2, 1]]) and np.array_equal(ls, li[:, [2, 1]])
+
+
+@pytest.mark.parametrize("n_buoys,n_windows", [(2, 5), (3, 4), (5, 3), (7, 3), (16, 2)])
+def test_buoy_counts_n4096(xc, n_buoys, n_windows):
+    """The fused window kernel's schedule depends on the buoy count (anchor runs, alternating stream
+    direction, batches of 7 resolved peaks, cfg4's 16 buoys = 120 pairs); every count against the
+    oracle on seeded windows, and more windows than one persistent workgroup pass would need."""
+    fs = 10e6
+    iq, delays = rm.synth.make_windows(n_windows, n_buoys, 4096, fs, seed=400 + n_buoys)
+    ri, rf, rp = orc.xcorr_batch_fast(iq, workers=4)
+    with xc.XcorrEngine(n_buoys, 4096, n_windows) as eng:
+        li, lf, pk = eng.correlate(iq)
+    assert li.shape == (n_windows, n_buoys * (n_buoys - 1) // 2)
+    margin = np.array([[orc.peak_margin(iq[w, i], iq[w, j]) for (i, j) in orc.pair_list(n_buoys)]
+                       for w in range(n_windows)])
+    _assert_parity(li, lf, pk, ri, rf, rp, margin)
+    true = delays[:, orc.pair_list(n_buoys)[:, 1]] - delays[:, orc.pair_list(n_buoys)[:, 0]]
+    assert np.all(np.abs(li + lf - true) < 0.5)
+
+
+def test_more_windows_than_compute_units(xc):
+    """Persistent workgroups loop over windows: 600 windows > 256 CUs exercises the second and third
+    pass of a workgroup (tables kept, record ring and exchange images reused across windows)."""
+    iq, _ = rm.synth.make_windows(600, 3, 4096, 2.4e6, seed=77)
+    ri, rf, rp = orc.xcorr_batch_fast(iq, workers=8)
+    with xc.XcorrEngine(3, 4096, 600) as eng:
+        li, lf, pk = eng.correlate(iq)
+        assert np.array_equal(li, ri)
+        ref = ri + rf
+        assert np.all(np.abs((li + lf.astype(np.float64)) - ref) <= TOL * np.maximum(np.abs(ref), 1.0))
+        eng.set_option("chunk_windows", 100)          # several launches, last one partial
+        li2, lf2, pk2 = eng.correlate(iq)
+        assert np.array_equal(li, li2) and np.array_equal(lf, lf2) and np.array_equal(pk, pk2)
