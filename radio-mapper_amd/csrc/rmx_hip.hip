@@ -619,7 +619,10 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
     // persistent workgroup: the tables above are loaded once, then windows blockIdx.x, +gridDim.x, ...
     for (int wl = blockIdx.x; wl < n_win; wl += gridDim.x) {
     C16 sa, sb;   // anchor spectrum X_i and the streamed X_j (scalar arrays: see C16)
-    const long wbase = (long)wl * B;
+    // spectrum scratch is per WORKGROUP, not per window: the persistent workgroup reuses the same
+    // B x 64 KiB for every window it processes (256 x 448 KiB = 115 MB live for the whole launch,
+    // resident in the 256 MB Infinity Cache, rewritten before most of it is ever evicted to HBM)
+    const long wbase = (long)blockIdx.x * B;
     const long obase = (first_window + wl) * (long)n_pairs;
     int seq = 0;         // transform counter: selects the exchange image
     int npair = 0;       // pair counter: selects the record slot (ring of kResSlots)
