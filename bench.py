@@ -109,16 +109,30 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal knobs for a one-GPU box (never set by the driver): RMX_BENCH_BACKEND=gloo and
+    # RMX_BENCH_SAME_DEVICE=1 run all ranks on cuda:0 so that the N>1 code path can be exercised
+    backend = os.environ.get("RMX_BENCH_BACKEND", "nccl")
+    dev_index = 0 if os.environ.get("RMX_BENCH_SAME_DEVICE") == "1" else local_rank
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
+
+    def barrier():
+        if backend == "nccl":
+            dist.barrier(device_ids=[dev_index])
+        else:
+            dist.barrier()
+
     n_gpus = world if world > 1 else 1
     if rank == 0:
         ge.build()
     if world > 1:
-        dist.barrier(device_ids=[local_rank])
-    dev = torch.device("cuda", local_rank)
+        barrier()
+    dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
 
     B, N, fs = args.buoys, 4096, 10e6
@@ -131,7 +145,7 @@ def main():
     frac = torch.zeros((W, P), dtype=torch.float32, device=dev)
     peak = torch.zeros((W, P), dtype=torch.float32, device=dev)
 
-    eng = xcorr.XcorrEngine(B, N, W, device=local_rank)
+    eng = xcorr.XcorrEngine(B, N, W, device=dev_index)
     stream = torch.cuda.current_stream()
     eng.set_stream(stream.cuda_stream)
     eng.set_option("timing", 1)   # HIP events around every launch, on the launch stream
@@ -142,7 +156,7 @@ def main():
     def sync_all():
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier(device_ids=[local_rank])
+            barrier()
             torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -166,7 +180,7 @@ def main():
         fwd_ms += tm["fwd_ms"]; fwd_n += tm["fwd_launches"]
         pair_ms += tm["pair_ms"]; pair_n += tm["pair_launches"]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed * 1e3 / args.steps
@@ -241,7 +255,7 @@ def main():
         print(json.dumps(line), flush=True)
     eng.close()
     if world > 1:
-        dist.barrier(device_ids=[local_rank])
+        barrier()
         dist.destroy_process_group()
 
 

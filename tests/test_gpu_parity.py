@@ -287,3 +287,18 @@ def test_more_windows_than_compute_units(xc):
         eng.set_option("chunk_windows", 100)          # several launches, last one partial
         li2, lf2, pk2 = eng.correlate(iq)
         assert np.array_equal(li, li2) and np.array_equal(lf, lf2) and np.array_equal(pk, pk2)
+
+
+def test_caf_four_step_length(xc):
+    """cfg5's shape in small: the Doppler grid on a window length that runs the four-step path
+    (N = 16384), against the oracle; one buoy carries a 2-bin Doppler offset."""
+    N, fs = 16384, 20e6
+    step = 0.5 / N
+    grid = (np.arange(5) - 2) * step
+    offs = np.array([0.0, 2.0, -1.0]) * step
+    iq, delays = rm.synth.make_windows(1, 3, N, fs, seed=55, doppler_cps=offs)
+    rd, ri, rf, rp = orc.caf_batch(iq, grid)
+    with xc.XcorrEngine(3, N, 1) as eng:
+        dop, li, lf, pk = eng.caf(iq, grid)
+    assert np.array_equal(dop, rd) and np.array_equal(dop[0], [4, 1, 0])
+    _assert_parity(li, lf, pk, ri, rf, rp)
