@@ -106,6 +106,29 @@ int rmx_caf_batch(rmx_ctx* ctx, const void* iq, int n_windows, const int32_t* pa
                   const double* doppler_cps, int n_dopplers, int32_t* dop_idx, int32_t* lag_int,
                   float* lag_frac, float* peak, unsigned flags);
 
+/* Batched hyperbolic position solve: the consumer of the lags.  One
+ * independent 3-unknown least-squares problem per window with the reference's objective
+ * (HyperbolicPositioning.triangulate_position, tdoa_processor.py:249-273),
+ *     f(p) = sum_q weight[w][q] * ( |p - b_j| - |p - b_i| - d[w][q] )^2 ,  (i, j) = pairs[q],
+ *     d = (lag_int + lag_frac) / sample_rate_hz * 299792458  (tdoa_processor.py:141,169-170),
+ * started from the centroid of the buoys (tdoa_processor.py:275-280).  The reference minimises f
+ * with scipy BFGS one window at a time; this entry uses a fixed Levenberg-Marquardt rule in float64
+ * (lambda_0 = 1e-3 on diag(J^T J); accept on decrease: lambda /= 3, floor 1e-12; reject: lambda *= 4;
+ * stop at an accepted step < 1e-4 m, lambda > 1e12, or max_iter iterations), restated on the CPU in
+ * oracle/solve_ref.py.
+ *   buoy_xyz   host double [n_buoys][3], ECEF metres (GeodeticCalculator.lat_lng_to_xyz)
+ *   pairs      host int32 [n_pairs][2] or NULL for all i<j in nested-loop order
+ *   lag_int / lag_frac   [n_windows][n_pairs], exactly what rmx_xcorr_batch wrote (device pointers
+ *              with RMX_IN_DEVICE: the two calls chain on the ctx stream without a host round trip)
+ *   weight     float [n_windows][n_pairs] = 1/(confidence+0.1) (tdoa_processor.py:267), or NULL = 1
+ *   pos        double [n_windows][3]  ECEF metres        cost    double [n_windows]  f at pos
+ *   iters      int32  [n_windows]     iterations used    (device pointers with RMX_OUT_DEVICE)
+ * accuracy_meters of the reference = sqrt(cost / n_pairs) (tdoa_processor.py:300). */
+int rmx_solve_batch(rmx_ctx* ctx, const double* buoy_xyz, int n_buoys, const int32_t* pairs, int n_pairs,
+                    const int32_t* lag_int, const float* lag_frac, const float* weight,
+                    double sample_rate_hz, int n_windows, int max_iter, double* pos, double* cost,
+                    int32_t* iters, unsigned flags);
+
 /* Wait for all work queued on the ctx stream. */
 int rmx_synchronize(rmx_ctx* ctx);
 

@@ -1019,6 +1019,110 @@ __global__ void k_caf_select(int d, int n, const int* __restrict__ lag_d, const 
     }
 }
 
+
+// ---- batched hyperbolic position solve (rmx_solve_batch) --------------------------------------------
+// One thread per window: 3 unknowns, P residuals, everything in float64 registers; the buoy table and
+// the pair list sit in LDS.  The lag arrays are read transposed-strided (lane = window), which is a
+// few hundred bytes per window and iteration: the kernel is latency-bound by its dependent
+// sqrt/divide chains, not by memory.
+constexpr int kSolveMaxBuoys = 64;
+constexpr int kSolveMaxPairs = kSolveMaxBuoys * (kSolveMaxBuoys - 1) / 2;
+__global__ __launch_bounds__(64) void k_solve(const double* __restrict__ buoy_xyz, int n_buoys,
+                                              const int* __restrict__ pairs, int n_pairs,
+                                              const int* __restrict__ lag_int, const float* __restrict__ lag_frac,
+                                              const float* __restrict__ weight, double metres_per_sample,
+                                              int n_windows, int max_iter, double* __restrict__ pos,
+                                              double* __restrict__ cost, int* __restrict__ iters) {
+#pragma clang fp contract(off)   // same roundings as the numpy restatement wherever the order is the same
+    __shared__ double sb[kSolveMaxBuoys * 3];
+    __shared__ short spair[kSolveMaxPairs * 2];
+    for (int i = threadIdx.x; i < n_buoys * 3; i += blockDim.x) sb[i] = buoy_xyz[i];
+    for (int i = threadIdx.x; i < n_pairs * 2; i += blockDim.x) spair[i] = (short)pairs[i];
+    __syncthreads();
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_windows) return;
+    const int* li = lag_int + (long)w * n_pairs;
+    const float* lf = lag_frac + (long)w * n_pairs;
+    const float* wg = weight ? weight + (long)w * n_pairs : nullptr;
+    double px = 0, py = 0, pz = 0;
+    for (int b = 0; b < n_buoys; ++b) { px += sb[3 * b]; py += sb[3 * b + 1]; pz += sb[3 * b + 2]; }
+    px /= n_buoys; py /= n_buoys; pz /= n_buoys;
+    auto f_at = [&](double x, double y, double z) -> double {
+        double f = 0;
+        for (int q = 0; q < n_pairs; ++q) {
+            const double* b1 = sb + 3 * spair[2 * q];
+            const double* b2 = sb + 3 * spair[2 * q + 1];
+            const double n1 = sqrt((x - b1[0]) * (x - b1[0]) + (y - b1[1]) * (y - b1[1]) + (z - b1[2]) * (z - b1[2]));
+            const double n2 = sqrt((x - b2[0]) * (x - b2[0]) + (y - b2[1]) * (y - b2[1]) + (z - b2[2]) * (z - b2[2]));
+            const double d = ((double)li[q] + (double)lf[q]) * metres_per_sample;
+            const double r = n2 - n1 - d;
+            f += (wg ? (double)wg[q] : 1.0) * r * r;
+        }
+        return f;
+    };
+    double lam = 1e-3;
+    double f = f_at(px, py, pz);
+    int it = 0;
+    while (it < max_iter) {
+        ++it;
+        double a00 = 0, a01 = 0, a02 = 0, a11 = 0, a12 = 0, a22 = 0, g0 = 0, g1 = 0, g2 = 0;
+        for (int q = 0; q < n_pairs; ++q) {
+            const double* b1 = sb + 3 * spair[2 * q];
+            const double* b2 = sb + 3 * spair[2 * q + 1];
+            const double v1x = px - b1[0], v1y = py - b1[1], v1z = pz - b1[2];
+            const double v2x = px - b2[0], v2y = py - b2[1], v2z = pz - b2[2];
+            const double n1 = sqrt(v1x * v1x + v1y * v1y + v1z * v1z);
+            const double n2 = sqrt(v2x * v2x + v2y * v2y + v2z * v2z);
+            const double d = ((double)li[q] + (double)lf[q]) * metres_per_sample;
+            const double r = n2 - n1 - d;
+            const double jx = v2x / n2 - v1x / n1, jy = v2y / n2 - v1y / n1, jz = v2z / n2 - v1z / n1;
+            const double ww = wg ? (double)wg[q] : 1.0;
+            a00 += ww * jx * jx; a01 += ww * jx * jy; a02 += ww * jx * jz;
+            a11 += ww * jy * jy; a12 += ww * jy * jz; a22 += ww * jz * jz;
+            g0 += ww * jx * r; g1 += ww * jy * r; g2 += ww * jz * r;
+        }
+        // (A + lam diag A) delta = -g by Cholesky; a failed factorisation counts as a rejected step
+        const double d00 = a00 * (1.0 + lam), d11 = a11 * (1.0 + lam), d22 = a22 * (1.0 + lam);
+        bool ok = d00 > 0.0;
+        const double l00 = sqrt(ok ? d00 : 1.0);
+        const double l10 = a01 / l00, l20 = a02 / l00;
+        const double t11 = d11 - l10 * l10;
+        ok = ok && t11 > 0.0;
+        const double l11 = sqrt(ok ? t11 : 1.0);
+        const double l21 = (a12 - l20 * l10) / l11;
+        const double t22 = d22 - l20 * l20 - l21 * l21;
+        ok = ok && t22 > 0.0;
+        const double l22 = sqrt(ok ? t22 : 1.0);
+        bool accepted = false;
+        double dn = 0.0;
+        if (ok) {
+            const double y0 = -g0 / l00;
+            const double y1 = (-g1 - l10 * y0) / l11;
+            const double y2 = (-g2 - l20 * y0 - l21 * y1) / l22;
+            const double dz = y2 / l22;
+            const double dy = (y1 - l21 * dz) / l11;
+            const double dx = (y0 - l10 * dy - l20 * dz) / l00;
+            const double fn = f_at(px + dx, py + dy, pz + dz);
+            if (fn < f) {
+                px += dx; py += dy; pz += dz;
+                f = fn;
+                accepted = true;
+                dn = sqrt(dx * dx + dy * dy + dz * dz);
+            }
+        }
+        if (accepted) {
+            lam = lam / 3.0 > 1e-12 ? lam / 3.0 : 1e-12;
+            if (dn < 1e-4) break;
+        } else {
+            lam *= 4.0;
+            if (lam > 1e12) break;
+        }
+    }
+    pos[3 * (long)w] = px; pos[3 * (long)w + 1] = py; pos[3 * (long)w + 2] = pz;
+    cost[w] = f;
+    iters[w] = it;
+}
+
 // ================================================================================================
 // host side
 // ================================================================================================
@@ -1058,6 +1162,9 @@ struct rmx_ctx {
     long g_slots_alloc = 0;
     int g_pairs_n = -1;
     std::vector<int32_t> g_pairs_plan;
+    // rmx_solve_batch work buffers
+    double* sv_buoys = nullptr;  int* sv_pairs = nullptr;  size_t sv_pairs_cap = 0;
+    void* sv_in = nullptr;  size_t sv_in_bytes = 0;  void* sv_out = nullptr;  size_t sv_out_bytes = 0;
     // CAF (rmx_caf_batch): child engine over the 2B-buoy augmented windows + work buffers
     rmx_ctx* caf_child = nullptr;
     float2* caf_aug = nullptr;  size_t caf_aug_bytes = 0;
@@ -1418,6 +1525,8 @@ void rmx_destroy(rmx_ctx* c) {
     for (void* p : {(void*)c->g_tw, (void*)c->g_tw1, (void*)c->g_tw2, (void*)c->g_thi, (void*)c->g_tlo, (void*)c->g_spec,
                     (void*)c->g_tmp, (void*)c->g_prod, (void*)c->g_pv, (void*)c->g_pk, (void*)c->g_pairs})
         if (p) (void)hipFree(p);
+    for (void* p : {(void*)c->sv_buoys, (void*)c->sv_pairs, c->sv_in, c->sv_out})
+        if (p) (void)hipFree(p);
     if (c->caf_child) rmx_destroy(c->caf_child);
     for (void* p : {(void*)c->caf_aug, (void*)c->caf_rot, (void*)c->caf_lag, (void*)c->caf_frac, (void*)c->caf_peak,
                     (void*)c->caf_dop})
@@ -1748,6 +1857,90 @@ int rmx_caf_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pair
         RMX_HIP(c, hipMemcpyAsync(lag_int, b_lag, out_elems * sizeof(int), hipMemcpyDeviceToHost, c->stream));
         RMX_HIP(c, hipMemcpyAsync(lag_frac, b_frac, out_elems * sizeof(float), hipMemcpyDeviceToHost, c->stream));
         RMX_HIP(c, hipMemcpyAsync(peak, b_peak, out_elems * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        RMX_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    return RMX_OK;
+}
+
+int rmx_solve_batch(rmx_ctx* c, const double* buoy_xyz, int n_buoys, const int32_t* pairs, int n_pairs,
+                    const int32_t* lag_int, const float* lag_frac, const float* weight, double sample_rate_hz,
+                    int n_windows, int max_iter, double* pos, double* cost, int32_t* iters, unsigned flags) {
+    if (!c) return RMX_E_INVAL;
+    if (!buoy_xyz || !lag_int || !lag_frac || !pos || !cost || !iters) return fail(c, RMX_E_INVAL, "NULL buffer");
+    if (n_buoys < 2 || n_buoys > rmx::kSolveMaxBuoys)
+        return fail(c, RMX_E_INVAL, "n_buoys %d not in 2..%d", n_buoys, rmx::kSolveMaxBuoys);
+    if (!(sample_rate_hz > 0.0)) return fail(c, RMX_E_INVAL, "sample_rate_hz must be positive");
+    if (n_windows < 0 || max_iter < 1) return fail(c, RMX_E_INVAL, "n_windows %d, max_iter %d", n_windows, max_iter);
+    const int all_pairs = n_buoys * (n_buoys - 1) / 2;
+    std::vector<int32_t> pl;
+    if (!pairs) {
+        if (n_pairs != 0 && n_pairs != all_pairs)
+            return fail(c, RMX_E_INVAL, "pairs == NULL needs n_pairs == 0 or %d, got %d", all_pairs, n_pairs);
+        n_pairs = all_pairs;
+        for (int i = 0; i < n_buoys; ++i)
+            for (int j = i + 1; j < n_buoys; ++j) { pl.push_back(i); pl.push_back(j); }
+    } else {
+        if (n_pairs < 1 || n_pairs > rmx::kSolveMaxPairs) return fail(c, RMX_E_INVAL, "n_pairs %d out of range", n_pairs);
+        for (int q = 0; q < 2 * n_pairs; ++q) {
+            if (pairs[q] < 0 || pairs[q] >= n_buoys) return fail(c, RMX_E_INVAL, "pair %d out of range", q / 2);
+            pl.push_back(pairs[q]);
+        }
+    }
+    if (n_windows == 0) return RMX_OK;
+    RMX_HIP(c, hipSetDevice(c->device));
+    if (!c->sv_buoys) RMX_HIP(c, hipMalloc((void**)&c->sv_buoys, rmx::kSolveMaxBuoys * 3 * sizeof(double)));
+    if (c->sv_pairs_cap < pl.size()) {
+        if (c->sv_pairs) (void)hipFree(c->sv_pairs);
+        c->sv_pairs = nullptr; c->sv_pairs_cap = 0;
+        RMX_HIP(c, hipMalloc((void**)&c->sv_pairs, pl.size() * sizeof(int)));
+        c->sv_pairs_cap = pl.size();
+    }
+    // (pageable host sources: these copies are synchronous with respect to the host buffers)
+    RMX_HIP(c, hipMemcpyAsync(c->sv_buoys, buoy_xyz, (size_t)n_buoys * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    RMX_HIP(c, hipMemcpyAsync(c->sv_pairs, pl.data(), pl.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    RMX_HIP(c, hipStreamSynchronize(c->stream));
+    const bool in_dev = flags & RMX_IN_DEVICE, out_dev = flags & RMX_OUT_DEVICE;
+    const size_t ne = (size_t)n_windows * n_pairs;
+    const int* d_li = lag_int;
+    const float* d_lf = lag_frac;
+    const float* d_wg = weight;
+    if (!in_dev) {
+        const size_t need = ne * 4 * 3;
+        if (c->sv_in_bytes < need) {
+            if (c->sv_in) (void)hipFree(c->sv_in);
+            c->sv_in = nullptr; c->sv_in_bytes = 0;
+            RMX_HIP(c, hipMalloc(&c->sv_in, need));
+            c->sv_in_bytes = need;
+        }
+        char* base = (char*)c->sv_in;
+        RMX_HIP(c, hipMemcpyAsync(base, lag_int, ne * 4, hipMemcpyHostToDevice, c->stream));
+        RMX_HIP(c, hipMemcpyAsync(base + ne * 4, lag_frac, ne * 4, hipMemcpyHostToDevice, c->stream));
+        if (weight) RMX_HIP(c, hipMemcpyAsync(base + ne * 8, weight, ne * 4, hipMemcpyHostToDevice, c->stream));
+        d_li = (const int*)base;
+        d_lf = (const float*)(base + ne * 4);
+        d_wg = weight ? (const float*)(base + ne * 8) : nullptr;
+    }
+    double *d_pos = pos, *d_cost = cost;
+    int* d_it = iters;
+    if (!out_dev) {
+        const size_t need = (size_t)n_windows * (3 * 8 + 8 + 4);
+        if (c->sv_out_bytes < need) {
+            if (c->sv_out) (void)hipFree(c->sv_out);
+            c->sv_out = nullptr; c->sv_out_bytes = 0;
+            RMX_HIP(c, hipMalloc(&c->sv_out, need));
+            c->sv_out_bytes = need;
+        }
+        d_pos = (double*)c->sv_out;
+        d_cost = d_pos + (size_t)n_windows * 3;
+        d_it = (int*)(d_cost + n_windows);
+    }
+    hipLaunchKernelGGL(rmx::k_solve, dim3((n_windows + 63) / 64), dim3(64), 0, c->stream, c->sv_buoys, n_buoys, c->sv_pairs,
+                       n_pairs, d_li, d_lf, d_wg, 299792458.0 / sample_rate_hz, n_windows, max_iter, d_pos, d_cost, d_it);
+    RMX_HIP(c, hipGetLastError());
+    if (!out_dev) {
+        RMX_HIP(c, hipMemcpyAsync(pos, d_pos, (size_t)n_windows * 3 * 8, hipMemcpyDeviceToHost, c->stream));
+        RMX_HIP(c, hipMemcpyAsync(cost, d_cost, (size_t)n_windows * 8, hipMemcpyDeviceToHost, c->stream));
+        RMX_HIP(c, hipMemcpyAsync(iters, d_it, (size_t)n_windows * 4, hipMemcpyDeviceToHost, c->stream));
         RMX_HIP(c, hipStreamSynchronize(c->stream));
     }
     return RMX_OK;

@@ -31,11 +31,13 @@ def _next_pow2(n: int) -> int:
 def make_windows(n_windows: int, n_buoys: int, n_samples: int, sample_rate_hz: float,
                  seed: int, snr_db: float = 10.0, bandwidth: float = 0.8,
                  rms: float = 32.0, quantise: bool = True, max_delay: float | None = None,
-                 return_u8: bool = False, doppler_cps: np.ndarray | None = None):
+                 return_u8: bool = False, doppler_cps: np.ndarray | None = None,
+                 delays: np.ndarray | None = None):
     """Returns (iq complex64 [W][B][N], delays float64 [W][B]) and, with return_u8, also the raw
     interleaved uint8 [W][B][2N] that decodes (u8 - 127.5) to exactly ``iq``.
 
     True lag of pair (i, j) is delays[:, j] - delays[:, i] (buoy2 - buoy1, tdoa_processor.py:51).
+    delays: optional [W][B] true delays in samples (default: uniform in +-max_delay).
     doppler_cps: optional [W][B] (or [B]) frequency offsets in cycles/sample applied per buoy as
     exp(+2j*pi*nu*n) after the delay (SURVEY.md section 8a-spec S8 / BASELINE cfg5).
     """
@@ -48,7 +50,11 @@ def make_windows(n_windows: int, n_buoys: int, n_samples: int, sample_rate_hz: f
     freqs = np.fft.fftfreq(Ns)  # cycles/sample
     mask = (np.abs(freqs) <= bandwidth / 2.0)
     out = np.empty((W, B, N), np.complex64)
-    delays = rng.uniform(-D, D, size=(W, B))
+    if delays is None:
+        delays = rng.uniform(-D, D, size=(W, B))
+    else:   # caller-supplied true delays in samples, e.g. from a transmitter/buoy geometry
+        delays = np.asarray(delays, np.float64).reshape(W, B)
+        assert np.abs(delays).max() <= margin - 1, "delays exceed the generator's margin"
     sig_amp = 1.0
     noise_amp = 10.0 ** (-snr_db / 20.0)
     scale = rms / np.sqrt(sig_amp ** 2 + noise_amp ** 2)

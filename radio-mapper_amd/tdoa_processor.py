@@ -270,6 +270,20 @@ class HyperbolicPositioning:
             return None
 
 
+    def triangulate_batch(self, engine, buoys: List[BuoyPosition], lag_int, lag_frac, sample_rate_hz: float,
+                          confidence=None, max_iter: int = 60):
+        """Batched form of triangulate_position on the GPU (rmx_solve_batch): one solve per window
+        from the lag arrays XcorrEngine.correlate returned for `buoys` (detection-list order, all
+        pairs i<j).  Same objective, start point and accuracy formula as the reference
+        (tdoa_processor.py:249-300).  Returns a list of (lat, lng, altitude, accuracy_meters)."""
+        xyz = np.array([GeodeticCalculator.lat_lng_to_xyz(b.lat, b.lng, b.altitude) for b in buoys])
+        weight = None if confidence is None else 1.0 / (np.asarray(confidence, np.float64) + 0.1)
+        pos, cost, _ = engine.solve(xyz, lag_int, lag_frac, sample_rate_hz, weight=weight, max_iter=max_iter)
+        n_meas = np.asarray(lag_int).shape[1]
+        return [GeodeticCalculator.xyz_to_lat_lng(*p) + (math.sqrt(max(c, 0.0) / n_meas),)
+                for p, c in zip(pos, cost)]
+
+
 # --------------------------------------------------------------------------------------------------
 # orchestrator (tdoa_processor.py:330-465)
 # --------------------------------------------------------------------------------------------------

@@ -65,6 +65,8 @@ def load_library():
     lib.rmx_xcorr_batch.restype = ci
     lib.rmx_caf_batch.argtypes = [vp, vp, ci, vp, ci, vp, ci, vp, vp, vp, vp, cu]
     lib.rmx_caf_batch.restype = ci
+    lib.rmx_solve_batch.argtypes = [vp, vp, ci, vp, ci, vp, vp, vp, C.c_double, ci, ci, vp, vp, vp, cu]
+    lib.rmx_solve_batch.restype = ci
     lib.rmx_synchronize.argtypes = [vp]
     lib.rmx_synchronize.restype = ci
     lib.rmx_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(ci), C.POINTER(C.c_float),
@@ -77,7 +79,7 @@ def load_library():
 
 
 EXPORTS = ["rmx_version", "rmx_device_count", "rmx_create", "rmx_destroy", "rmx_last_error",
-           "rmx_set_stream", "rmx_set_option", "rmx_xcorr_batch", "rmx_caf_batch", "rmx_synchronize",
+           "rmx_set_stream", "rmx_set_option", "rmx_xcorr_batch", "rmx_caf_batch", "rmx_solve_batch", "rmx_synchronize",
            "rmx_last_timing", "rmx_scratch_bytes"]
 
 
@@ -212,6 +214,34 @@ class XcorrEngine:
             dop.ctypes.data_as(C.c_void_p), lag_int.ctypes.data_as(C.c_void_p),
             lag_frac.ctypes.data_as(C.c_void_p), peak.ctypes.data_as(C.c_void_p), flags))
         return dop, lag_int, lag_frac, peak
+
+    def solve(self, buoy_xyz, lag_int, lag_frac, sample_rate_hz: float, weight=None,
+              pairs: Optional[np.ndarray] = None, max_iter: int = 60):
+        """Batched hyperbolic position solve (rmx_solve_batch), host arrays in and out.
+        buoy_xyz [B][3] ECEF metres; lag_int/lag_frac [W][P] as returned by correlate().
+        Returns (pos float64 [W][3], cost float64 [W], iters int32 [W])."""
+        bx = np.ascontiguousarray(buoy_xyz, dtype=np.float64).reshape(-1, 3)
+        li = np.ascontiguousarray(lag_int, dtype=np.int32)
+        lf = np.ascontiguousarray(lag_frac, dtype=np.float32)
+        W, P = li.shape
+        wp = None
+        if weight is not None:
+            wgt = np.ascontiguousarray(weight, dtype=np.float32)
+            wp = wgt.ctypes.data_as(C.c_void_p)
+        pp = None
+        if pairs is not None:
+            pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+            pp = pairs.ctypes.data_as(C.c_void_p)
+        pos = np.zeros((W, 3), np.float64)
+        cost = np.zeros(W, np.float64)
+        iters = np.zeros(W, np.int32)
+        if W == 0:
+            return pos, cost, iters
+        self._check(self._lib.rmx_solve_batch(
+            self._ctx, bx.ctypes.data_as(C.c_void_p), bx.shape[0], pp, P, li.ctypes.data_as(C.c_void_p),
+            lf.ctypes.data_as(C.c_void_p), wp, float(sample_rate_hz), W, int(max_iter),
+            pos.ctypes.data_as(C.c_void_p), cost.ctypes.data_as(C.c_void_p), iters.ctypes.data_as(C.c_void_p), 0))
+        return pos, cost, iters
 
     def correlate_device(self, iq_ptr: int, n_windows: int, lag_int_ptr: int, lag_frac_ptr: int,
                          peak_ptr: int, pairs: Optional[np.ndarray] = None, u8: bool = False):
