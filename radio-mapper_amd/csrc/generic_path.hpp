@@ -33,35 +33,74 @@ __device__ __forceinline__ float2 g_cmulc(float2 a, float2 b) {   // a * conj(b)
     return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
 }
 
-// In-place radix-2 transforms of one row of R = 2^logR points held in LDS; tw[k] = W_R^k, k < R/2.
+// In-place transforms of one row of R = 2^logR points held in LDS; tw[k] = W_R^k, k < R/2.  Two
+// radix-2 stages are fused per pass over the row (a radix-4 butterfly in registers: one LDS read and
+// write of the row and one barrier per TWO stages; an odd logR leaves one plain radix-2 stage); the
+// data flow, and with it the output order, is that of the radix-2 network.
 // DIF: natural in -> bit-reversed out (forward, W = exp(-2 pi i / R)).
 __device__ __forceinline__ void lds_dif(float2* x, int logR, const float2* __restrict__ tw, int tid, int nthr) {
-    const int half_n = 1 << (logR - 1);
-    for (int s = logR - 1; s >= 0; --s) {
-        const int half = 1 << s;
+    int s = logR - 1;
+    for (; s >= 1; s -= 2) {          // stages s (half = 2q) and s-1 (half = q)
+        const int q = 1 << (s - 1);
+        const int quads = 1 << (logR - 2);
+        for (int i = tid; i < quads; i += nthr) {
+            const int l = i & (q - 1);
+            const int j = ((i >> (s - 1)) << (s + 1)) | l;
+            const float2 x0 = x[j], x1 = x[j + q], x2 = x[j + 2 * q], x3 = x[j + 3 * q];
+            const float2 wa = tw[l << (logR - 1 - s)];          // stage s, element j
+            const float2 wb = make_float2(wa.y, -wa.x);         // stage s, element j+q: wa * W_R^(R/4) = -i wa
+            const float2 w2 = tw[l << (logR - s)];              // stage s-1
+            const float2 a0 = make_float2(x0.x + x2.x, x0.y + x2.y);
+            const float2 a2 = g_cmul(make_float2(x0.x - x2.x, x0.y - x2.y), wa);
+            const float2 a1 = make_float2(x1.x + x3.x, x1.y + x3.y);
+            const float2 a3 = g_cmul(make_float2(x1.x - x3.x, x1.y - x3.y), wb);
+            x[j] = make_float2(a0.x + a1.x, a0.y + a1.y);
+            x[j + q] = g_cmul(make_float2(a0.x - a1.x, a0.y - a1.y), w2);
+            x[j + 2 * q] = make_float2(a2.x + a3.x, a2.y + a3.y);
+            x[j + 3 * q] = g_cmul(make_float2(a2.x - a3.x, a2.y - a3.y), w2);
+        }
+        __syncthreads();
+    }
+    if (s == 0) {                     // odd logR: the last stage (half = 1, twiddle 1)
+        const int half_n = 1 << (logR - 1);
         for (int i = tid; i < half_n; i += nthr) {
-            const int lo = i & (half - 1);
-            const int j = ((i >> s) << (s + 1)) | lo;
-            const float2 a = x[j], b = x[j + half];
-            const float2 w = tw[lo << (logR - 1 - s)];
-            x[j] = make_float2(a.x + b.x, a.y + b.y);
-            x[j + half] = g_cmul(make_float2(a.x - b.x, a.y - b.y), w);
+            const float2 a = x[2 * i], b = x[2 * i + 1];
+            x[2 * i] = make_float2(a.x + b.x, a.y + b.y);
+            x[2 * i + 1] = make_float2(a.x - b.x, a.y - b.y);
         }
         __syncthreads();
     }
 }
 // DIT with conjugated twiddles: bit-reversed in -> natural out (inverse, unnormalised).
 __device__ __forceinline__ void lds_dit_inv(float2* x, int logR, const float2* __restrict__ tw, int tid, int nthr) {
-    const int half_n = 1 << (logR - 1);
-    for (int s = 0; s < logR; ++s) {
-        const int half = 1 << s;
+    int s = 0;
+    if (logR & 1) {                   // odd logR: the first stage (half = 1, twiddle 1) on its own
+        const int half_n = 1 << (logR - 1);
         for (int i = tid; i < half_n; i += nthr) {
-            const int lo = i & (half - 1);
-            const int j = ((i >> s) << (s + 1)) | lo;
-            const float2 a = x[j];
-            const float2 b = g_cmulc(x[j + half], tw[lo << (logR - 1 - s)]);
-            x[j] = make_float2(a.x + b.x, a.y + b.y);
-            x[j + half] = make_float2(a.x - b.x, a.y - b.y);
+            const float2 a = x[2 * i], b = x[2 * i + 1];
+            x[2 * i] = make_float2(a.x + b.x, a.y + b.y);
+            x[2 * i + 1] = make_float2(a.x - b.x, a.y - b.y);
+        }
+        __syncthreads();
+        s = 1;
+    }
+    for (; s + 1 < logR; s += 2) {    // stages s (half = q) and s+1 (half = 2q)
+        const int q = 1 << s;
+        const int quads = 1 << (logR - 2);
+        for (int i = tid; i < quads; i += nthr) {
+            const int l = i & (q - 1);
+            const int j = ((i >> s) << (s + 2)) | l;
+            const float2 w1 = tw[l << (logR - 1 - s)];          // stage s
+            const float2 wa = tw[l << (logR - 2 - s)];          // stage s+1, element j
+            const float2 wb = make_float2(wa.y, -wa.x);         // stage s+1, element j+q: -i wa (conjugated below)
+            const float2 x0 = x[j], x1 = g_cmulc(x[j + q], w1), x2 = x[j + 2 * q], x3 = g_cmulc(x[j + 3 * q], w1);
+            const float2 a0 = make_float2(x0.x + x1.x, x0.y + x1.y), a1 = make_float2(x0.x - x1.x, x0.y - x1.y);
+            const float2 b0 = g_cmulc(make_float2(x2.x + x3.x, x2.y + x3.y), wa);
+            const float2 b1 = g_cmulc(make_float2(x2.x - x3.x, x2.y - x3.y), wb);
+            x[j] = make_float2(a0.x + b0.x, a0.y + b0.y);
+            x[j + 2 * q] = make_float2(a0.x - b0.x, a0.y - b0.y);
+            x[j + q] = make_float2(a1.x + b1.x, a1.y + b1.y);
+            x[j + 3 * q] = make_float2(a1.x - b1.x, a1.y - b1.y);
         }
         __syncthreads();
     }
