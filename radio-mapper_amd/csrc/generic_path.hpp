@@ -11,8 +11,9 @@
 //                    "digit-reversed" order the forward pass leaves it in (the product is pointwise
 //                    and the inverse pass undoes the same permutation):
 //                      forward : T, rows(L1, DIF) * W_L^(n2 k1), T, rows(L2, DIF)
-//                      inverse : rows(L2, DIT) * W_L^-(n2 k1), T, rows(L1, DIT), T  -> r[0..L) natural
-//                      g_absmax (partial argmax in 'full' order) + g_final (reduce, 3 taps, parabola)
+//                      inverse : [X_j conj(X_i) formed on load] rows(L2, DIT) * W_L^-(n2 k1), T, rows(L1, DIT)
+//                                -> r as [n2][n1]; g_absmax (partial argmax in 'full' order, reading that
+//                                layout in place) + g_final (reduce, 3 taps, parabola)
 // Twiddles: W_R^k tables per row length computed in double on the host; the large W_L^(a*b) factor of
 // the four-step is the product of two table entries (a*b mod L split into high and low digits).
 #pragma once
@@ -229,27 +230,50 @@ __device__ __forceinline__ float2 big_tw(long m, int lo_bits, const float2* __re
     return g_cmul(thi[m >> lo_bits], tlo[m & ((1L << lo_bits) - 1)]);
 }
 
-// MODE 0: rows are the zero-padded window itself transposed: handled by the caller (plain rows)
-// Row transforms of length R over a [batch * n_rows][R] array, in place.
+// Row transforms of length R over a [batch * n_rows][R] array, in place.  A workgroup takes
+// 256 / min(256, R/4) rows at once (short rows would leave most of its threads idle).
 //   FWD = true : DIF; then (TW) multiply position q by W_L^(row_in_batch * brev(q))
 //   FWD = false: DIT inverse; then (TW) multiply position n by conj W_L^(n * brev(row_in_batch))
-template <bool FWD, bool TW>
+//   PROD (inverse only): the row is not read from `data` but formed on the fly as
+//        X_j[row] conj(X_i[row]) from the spectra (slot = window-in-chunk * n_pairs + pair), which
+//        saves the product's own pass through HBM; the result is written to `data`.
+template <bool FWD, bool TW, bool PROD = false>
 __global__ __launch_bounds__(kGThreads) void g_rows(float2* __restrict__ data, const float2* __restrict__ tw, int logR,
                                                     int n_rows, int row_bits, long Ltot, int lo_bits,
                                                     const float2* __restrict__ thi,
-                                                    const float2* __restrict__ tlo, float scale) {
+                                                    const float2* __restrict__ tlo, float scale, long total_rows,
+                                                    const float2* __restrict__ spec = nullptr,
+                                                    const GPair* __restrict__ pairs = nullptr, int n_pairs = 0,
+                                                    int n_buoys = 0) {
     extern __shared__ __attribute__((aligned(16))) char gsm[];
-    float2* x = reinterpret_cast<float2*>(gsm);
-    const int R = 1 << logR, tid = threadIdx.x;
-    float2* row = data + (long)blockIdx.x * R;
-    const int rib = blockIdx.x % n_rows;   // row index inside its batch element
-    for (int n = tid; n < R; n += kGThreads) x[n] = row[n];
+    const int R = 1 << logR;
+    const int tpr = (R >> 2) < kGThreads ? ((R >> 2) > 0 ? (R >> 2) : 1) : kGThreads;   // threads per row
+    const int rpw = kGThreads / tpr;                                                   // rows per workgroup
+    const int g = threadIdx.x / tpr, tid = threadIdx.x % tpr;
+    const long ridx = (long)blockIdx.x * rpw + g;
+    const bool live = ridx < total_rows;
+    float2* x = reinterpret_cast<float2*>(gsm) + (long)g * R;
+    float2* row = data + ridx * R;
+    const int rib = (int)(ridx & (n_rows - 1));   // row index inside its batch element (n_rows = 2^row_bits)
+    if (live) {
+        if constexpr (PROD) {
+            const long slot = ridx >> row_bits;
+            const int wl = (int)(slot / n_pairs), q = (int)(slot % n_pairs);
+            const GPair pr = pairs[q];
+            const float2* xi = spec + (((long)wl * n_buoys + pr.i) * n_rows + rib) * R;
+            const float2* xj = spec + (((long)wl * n_buoys + pr.j) * n_rows + rib) * R;
+            for (int n = tid; n < R; n += tpr) x[n] = g_cmulc(xj[n], xi[n]);
+        } else {
+            for (int n = tid; n < R; n += tpr) x[n] = row[n];
+        }
+    }
     __syncthreads();
-    if (FWD) lds_dif(x, logR, tw, tid, kGThreads); else lds_dit_inv(x, logR, tw, tid, kGThreads);
-    for (int n = tid; n < R; n += kGThreads) {
+    if (FWD) lds_dif(x, logR, tw, tid, tpr); else lds_dit_inv(x, logR, tw, tid, tpr);
+    if (!live) return;
+    for (int n = tid; n < R; n += tpr) {
         float2 v = x[n];
         if (TW) {
-            const long m = FWD ? ((long)rib * brev(n, logR)) % Ltot : ((long)n * brev(rib, row_bits)) % Ltot;
+            const long m = (FWD ? ((long)rib * brev(n, logR)) : ((long)n * brev(rib, row_bits))) & (Ltot - 1);
             const float2 w = big_tw(m, lo_bits, thi, tlo);
             v = FWD ? g_cmul(v, w) : g_cmulc(v, w);
         }
@@ -283,32 +307,25 @@ __global__ void g_load_transposed(const void* __restrict__ iq, float2* __restric
         out[ooff + (long)(c0 + c) * L1 + r0 + threadIdx.x] = tile[threadIdx.x][c];
 }
 
-// prod[slot][m] = X_j[m] conj(X_i[m])
-__global__ void g_product(const float2* __restrict__ spec, float2* __restrict__ prod,
-                          const GPair* __restrict__ pairs, int n_pairs, int n_buoys, long L) {
-    const int slot = blockIdx.y;   // window-in-chunk * n_pairs + pair
-    const int wl = slot / n_pairs, q = slot % n_pairs;
-    const GPair pr = pairs[q];
-    const float2* xi = spec + ((long)wl * n_buoys + pr.i) * L;
-    const float2* xj = spec + ((long)wl * n_buoys + pr.j) * L;
-    float2* o = prod + (long)slot * L;
-    for (long m = (long)blockIdx.x * blockDim.x + threadIdx.x; m < L; m += (long)gridDim.x * blockDim.x)
-        o[m] = g_cmulc(xj[m], xi[m]);
+// partial argmax of |r|^2 in 'full' order: grid (parts, slots).  r is the inverse transform as the
+// last row pass leaves it, [n2][n1] (position p = n2*L1 + n1 holds circular index m = n1*L2 + n2):
+// reading it in place saves the transpose back to natural order (l1 = 0 means natural order).
+__device__ __forceinline__ long nat_to_pos(long m, int l1, int l2) {
+    return l1 == 0 ? m : ((m & ((1L << l2) - 1)) << l1) | (m >> l2);
 }
-
-// partial argmax of |r|^2 in 'full' order: grid (parts, slots)
-__global__ __launch_bounds__(kGThreads) void g_absmax(const float2* __restrict__ r, int N, float* __restrict__ pv,
-                                                      int* __restrict__ pk) {
+__global__ __launch_bounds__(kGThreads) void g_absmax(const float2* __restrict__ r, int N, int l1, int l2,
+                                                      float* __restrict__ pv, int* __restrict__ pk) {
     __shared__ float sv[kGThreads];
     __shared__ int sk[kGThreads];
     const long L = 2L * N;
     const float2* x = r + (long)blockIdx.y * L;
     float best = -1.0f;
     int bk = 0x7fffffff;
-    for (long m = (long)blockIdx.x * kGThreads + threadIdx.x; m < L; m += (long)gridDim.x * kGThreads) {
+    for (long p = (long)blockIdx.x * kGThreads + threadIdx.x; p < L; p += (long)gridDim.x * kGThreads) {
+        const long m = l1 == 0 ? p : ((p & ((1L << l1) - 1)) << l2) | (p >> l1);
         const int k = full_index((int)m, N);
         if (k < 0) continue;
-        const float2 e = x[m];
+        const float2 e = x[p];
         const float v = e.x * e.x + e.y * e.y;
         if (v > best || (v == best && k < bk)) { best = v; bk = k; }
     }
@@ -319,9 +336,9 @@ __global__ __launch_bounds__(kGThreads) void g_absmax(const float2* __restrict__
     }
 }
 
-__global__ void g_final(const float2* __restrict__ r, int N, const float* __restrict__ pv, const int* __restrict__ pk,
-                        int parts, int n_slots, long out_base, float out_scale, int* __restrict__ lag_int,
-                        float* __restrict__ lag_frac, float* __restrict__ peak) {
+__global__ void g_final(const float2* __restrict__ r, int N, int l1, int l2, const float* __restrict__ pv,
+                        const int* __restrict__ pk, int parts, int n_slots, long out_base, float out_scale,
+                        int* __restrict__ lag_int, float* __restrict__ lag_frac, float* __restrict__ peak) {
     const int slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= n_slots) return;
     float best = -1.0f;
@@ -335,7 +352,7 @@ __global__ void g_final(const float2* __restrict__ r, int N, const float* __rest
     const float b = sqrtf(best) * out_scale;
     float frac = 0.0f;
     if (bk > 0 && bk < 2 * N - 2) {
-        const float2 ra = x[circ_index(bk - 1, N)], rc = x[circ_index(bk + 1, N)];
+        const float2 ra = x[nat_to_pos(circ_index(bk - 1, N), l1, l2)], rc = x[nat_to_pos(circ_index(bk + 1, N), l1, l2)];
         frac = parabola(sqrtf(ra.x * ra.x + ra.y * ra.y) * out_scale, b, sqrtf(rc.x * rc.x + rc.y * rc.y) * out_scale);
     }
     lag_int[out_base + slot] = bk - (N - 1);

@@ -1409,21 +1409,29 @@ static int generic_batch(rmx_ctx* c, const void* d_iq, int n_windows, int n_pair
         else
             hipLaunchKernelGGL(g_load_transposed<false>, dim3(L2 / 32, L1 / 32, items), tb, 0, st, d_iq, c->g_tmp, N, L1, L2,
                                first_item);
-        hipLaunchKernelGGL((g_rows<true, true>), dim3(items * L2), dim3(kGThreads), (size_t)L1 * 8, st, c->g_tmp, c->g_tw1,
-                           l1, L2, l2, L, c->g_lo_bits, c->g_thi, c->g_tlo, 1.0f);
+        auto rows_grid = [](long rows, int R) -> dim3 {      // workgroups for `rows` rows of length R
+            const int tpr = (R >> 2) < kGThreads ? ((R >> 2) > 0 ? (R >> 2) : 1) : kGThreads;
+            const int rpw = kGThreads / tpr;
+            return dim3((unsigned)((rows + rpw - 1) / rpw));
+        };
+        auto rows_lds = [](int R) -> size_t {
+            const int tpr = (R >> 2) < kGThreads ? ((R >> 2) > 0 ? (R >> 2) : 1) : kGThreads;
+            return (size_t)(kGThreads / tpr) * R * 8;
+        };
+        hipLaunchKernelGGL((g_rows<true, true>), rows_grid((long)items * L2, L1), dim3(kGThreads), rows_lds(L1), st, c->g_tmp,
+                           c->g_tw1, l1, L2, l2, L, c->g_lo_bits, c->g_thi, c->g_tlo, 1.0f, (long)items * L2);
         hipLaunchKernelGGL(g_transpose, dim3(L1 / 32, L2 / 32, items), tb, 0, st, c->g_tmp, c->g_spec, L2, L1);
-        hipLaunchKernelGGL((g_rows<true, false>), dim3(items * L1), dim3(kGThreads), (size_t)L2 * 8, st, c->g_spec,
-                           c->g_tw2, l2, L1, l1, L, c->g_lo_bits, c->g_thi, c->g_tlo, fwd_scale);
-        // pairs: product, rows(L2)^-1 * conj W_L^(n2 k1), T, rows(L1)^-1, T
-        hipLaunchKernelGGL(g_product, dim3(256, slots), dim3(256), 0, st, c->g_spec, c->g_prod, c->g_pairs, n_pairs, B, L);
-        hipLaunchKernelGGL((g_rows<false, true>), dim3(slots * L1), dim3(kGThreads), (size_t)L2 * 8, st, c->g_prod,
-                           c->g_tw2, l2, L1, l1, L, c->g_lo_bits, c->g_thi, c->g_tlo, 1.0f);
+        hipLaunchKernelGGL((g_rows<true, false>), rows_grid((long)items * L1, L2), dim3(kGThreads), rows_lds(L2), st, c->g_spec,
+                           c->g_tw2, l2, L1, l1, L, c->g_lo_bits, c->g_thi, c->g_tlo, fwd_scale, (long)items * L1);
+        // pairs: [product on load] rows(L2)^-1 * conj W_L^(n2 k1), T, rows(L1)^-1; argmax on the [n2][n1] result
+        hipLaunchKernelGGL((g_rows<false, true, true>), rows_grid((long)slots * L1, L2), dim3(kGThreads), rows_lds(L2), st,
+                           c->g_prod, c->g_tw2, l2, L1, l1, L, c->g_lo_bits, c->g_thi, c->g_tlo, 1.0f, (long)slots * L1,
+                           c->g_spec, c->g_pairs, n_pairs, B);
         hipLaunchKernelGGL(g_transpose, dim3(L2 / 32, L1 / 32, slots), tb, 0, st, c->g_prod, c->g_tmp, L1, L2);
-        hipLaunchKernelGGL((g_rows<false, false>), dim3(slots * L2), dim3(kGThreads), (size_t)L1 * 8, st, c->g_tmp,
-                           c->g_tw1, l1, L2, l2, L, c->g_lo_bits, c->g_thi, c->g_tlo, 1.0f);
-        hipLaunchKernelGGL(g_transpose, dim3(L1 / 32, L2 / 32, slots), tb, 0, st, c->g_tmp, c->g_prod, L2, L1);
-        hipLaunchKernelGGL(g_absmax, dim3(64, slots), dim3(kGThreads), 0, st, c->g_prod, N, c->g_pv, c->g_pk);
-        hipLaunchKernelGGL(g_final, dim3((slots + 63) / 64), dim3(64), 0, st, c->g_prod, N, c->g_pv, c->g_pk, 64, slots,
+        hipLaunchKernelGGL((g_rows<false, false>), rows_grid((long)slots * L2, L1), dim3(kGThreads), rows_lds(L1), st, c->g_tmp,
+                           c->g_tw1, l1, L2, l2, L, c->g_lo_bits, c->g_thi, c->g_tlo, 1.0f, (long)slots * L2);
+        hipLaunchKernelGGL(g_absmax, dim3(64, slots), dim3(kGThreads), 0, st, c->g_tmp, N, l1, l2, c->g_pv, c->g_pk);
+        hipLaunchKernelGGL(g_final, dim3((slots + 63) / 64), dim3(64), 0, st, c->g_tmp, N, l1, l2, c->g_pv, c->g_pk, 64, slots,
                            (long)w0 * n_pairs, out_scale, d_lag, d_frac, d_peak);
         RMX_HIP(c, hipGetLastError());
     }
