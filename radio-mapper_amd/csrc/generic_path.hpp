@@ -269,15 +269,29 @@ __global__ __launch_bounds__(kGThreads) void g_rows(float2* __restrict__ data, c
     }
     __syncthreads();
     if (FWD) lds_dif(x, logR, tw, tid, tpr); else lds_dit_inv(x, logR, tw, tid, tpr);
-    if (!live) return;
-    for (int n = tid; n < R; n += tpr) {
-        float2 v = x[n];
-        if (TW) {
-            const long m = (FWD ? ((long)rib * brev(n, logR)) : ((long)n * brev(rib, row_bits))) & (Ltot - 1);
-            const float2 w = big_tw(m, lo_bits, thi, tlo);
-            v = FWD ? g_cmul(v, w) : g_cmulc(v, w);
+    if constexpr (TW) {
+        // W_L^(c*e) for this row's fixed multiplier c and every exponent e < R, as the product of two
+        // per-row LDS tables T1[e & (2^a - 1)] * T2[e >> a] (2^a + R/2^a big-table lookups per row
+        // instead of two uncoalesced gathers per element)
+        const int a = logR >> 1, n1 = 1 << a, n2 = R >> a;
+        float2* t1 = reinterpret_cast<float2*>(gsm) + (long)(kGThreads / tpr) * R + (long)g * (n1 + n2);
+        float2* t2 = t1 + n1;
+        const long c = FWD ? (long)rib : (long)brev(rib, row_bits);
+        for (int e = tid; e < n1 + n2; e += tpr) {
+            const long ee = e < n1 ? (long)e : ((long)(e - n1) << a);
+            t1[e] = big_tw((c * ee) & (Ltot - 1), lo_bits, thi, tlo);
         }
-        row[n] = make_float2(v.x * scale, v.y * scale);
+        __syncthreads();
+        if (!live) return;
+        for (int n = tid; n < R; n += tpr) {
+            const int e = FWD ? brev(n, logR) : n;
+            const float2 w = g_cmul(t1[e & (n1 - 1)], t2[e >> a]);
+            const float2 v = FWD ? g_cmul(x[n], w) : g_cmulc(x[n], w);
+            row[n] = make_float2(v.x * scale, v.y * scale);
+        }
+    } else {
+        if (!live) return;
+        for (int n = tid; n < R; n += tpr) row[n] = make_float2(x[n].x * scale, x[n].y * scale);
     }
 }
 

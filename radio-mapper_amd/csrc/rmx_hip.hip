@@ -1414,9 +1414,12 @@ static int generic_batch(rmx_ctx* c, const void* d_iq, int n_windows, int n_pair
             const int rpw = kGThreads / tpr;
             return dim3((unsigned)((rows + rpw - 1) / rpw));
         };
-        auto rows_lds = [](int R) -> size_t {
+        auto rows_lds = [](int R) -> size_t {               // rows + per-row twiddle tables (TW passes)
             const int tpr = (R >> 2) < kGThreads ? ((R >> 2) > 0 ? (R >> 2) : 1) : kGThreads;
-            return (size_t)(kGThreads / tpr) * R * 8;
+            int logR = 0;
+            while ((1 << logR) < R) ++logR;
+            const int a = logR >> 1;
+            return (size_t)(kGThreads / tpr) * ((size_t)R + (1 << a) + (R >> a)) * 8;
         };
         hipLaunchKernelGGL((g_rows<true, true>), rows_grid((long)items * L2, L1), dim3(kGThreads), rows_lds(L1), st, c->g_tmp,
                            c->g_tw1, l1, L2, l2, L, c->g_lo_bits, c->g_thi, c->g_tlo, 1.0f, (long)items * L2);
