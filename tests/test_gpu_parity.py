@@ -256,7 +256,7 @@ def test_caf_golden(xc, golden_dir, name):
         assert np.array_equal(ds, dop[:, [2, 1]]) and np.array_equal(ls, li[:, [2, 1]])
 
 
-@pytest.mark.parametrize("n_buoys,n_windows", [(2, 5), (3, 4), (5, 3), (7, 3), (16, 2)])
+@pytest.mark.parametrize("n_buoys,n_windows", [(2, 5), (3, 4), (5, 3), (7, 3), (16, 2), (32, 1)])
 def test_buoy_counts_n4096(xc, n_buoys, n_windows):
     """The fused window kernel's schedule depends on the buoy count (anchor runs, alternating stream
     direction, batches of 7 resolved peaks, cfg4's 16 buoys = 120 pairs); every count against the
@@ -302,3 +302,32 @@ def test_caf_four_step_length(xc):
         dop, li, lf, pk = eng.caf(iq, grid)
     assert np.array_equal(dop, rd) and np.array_equal(dop[0], [4, 1, 0])
     _assert_parity(li, lf, pk, ri, rf, rp)
+
+
+def test_error_codes_on_device(xc):
+    """The C functions return a negative code and a message, never abort (the reference's 'log and
+    return' convention, tdoa_processor.py:151-153, restated at the C boundary)."""
+    import ctypes as C
+    lib = xc.load_library()
+    with xc.XcorrEngine(3, 4096, 4) as eng:
+        iq = np.zeros((5, 3, 4096), np.complex64)
+        with pytest.raises(xc.RmxError) as e:
+            eng.correlate(iq)                                    # n_windows > max_windows
+        assert e.value.code == -1 and "max_windows" in str(e.value)
+        with pytest.raises(xc.RmxError):
+            eng.correlate(iq[:2], pairs=np.array([[0, 3]], np.int32))   # buoy index out of range
+        with pytest.raises(ValueError):
+            eng.correlate(np.zeros((2, 3, 1000), np.complex64))  # wrong window length (binding check)
+        assert lib.rmx_xcorr_batch(eng._ctx, None, 1, None, 3, None, None, None, 0) == -1
+        with pytest.raises(xc.RmxError):
+            eng.caf(iq[:2], [])                                  # empty Doppler grid
+        with pytest.raises(xc.RmxError):
+            eng.set_option("no_such_option", 1)
+        with pytest.raises(xc.RmxError):
+            eng.solve(np.zeros((3, 3)), np.zeros((2, 3), np.int32), np.zeros((2, 3), np.float32), 0.0)   # fs = 0
+        # the engine is still usable after errors
+        li, lf, pk = eng.correlate(iq[:2])
+        assert li.shape == (2, 3) and np.all(li == -(4096 - 1)) and np.all(pk == 0.0)   # all-zero windows
+    with pytest.raises(xc.RmxError) as e:
+        xc.XcorrEngine(3, 4096, 4, device=99)
+    assert e.value.code == -1
