@@ -6,14 +6,19 @@
 //                      g_fwd_small   (window, buoy)  : radix-2 DIF, spectrum left in bit-reversed order
 //                      g_pair_small  (window, pair)  : X_j conj(X_i) -> radix-2 DIT (takes bit-reversed
 //                                                      input, natural output) -> |.|, argmax, parabola
-//   L = 2N  > 8192   four-step transform through HBM, L = L1 x L2 (both <= 4096), every pass a batch
-//                    of LDS row transforms between tiled transposes; the spectrum stays in the
-//                    "digit-reversed" order the forward pass leaves it in (the product is pointwise
-//                    and the inverse pass undoes the same permutation):
-//                      forward : T, rows(L1, DIF) * W_L^(n2 k1), T, rows(L2, DIF)
-//                      inverse : [X_j conj(X_i) formed on load] rows(L2, DIT) * W_L^-(n2 k1), T, rows(L1, DIT)
-//                                -> r as [n2][n1]; g_absmax (partial argmax in 'full' order, reading that
-//                                layout in place) + g_final (reduce, 3 taps, parabola)
+//   L = 2N  > 8192   four-step transform through HBM in two passes per transform, no transposes: the
+//                    sequence is the row-major matrix [L1][L2] (L1 <= 1024 columns-length, L2 = L/L1
+//                    <= 8192), n = n1*L2 + n2:
+//                      forward : g_cols_fwd  tiles of 16 columns x all L1 rows in LDS (up to 128 KiB of
+//                                            the CU's 160 KiB): zero-padded load, DIF over n1,
+//                                            * W_L^(n2 k1), store [k1'][n2]
+//                                g_rows      DIF over n2 in place -> spectrum [k1'][k2'] (digit-reversed;
+//                                            the product is pointwise and the inverse undoes the order)
+//                      inverse : g_rows      X_j conj(X_i) formed on load, DIT over k2', * conj W_L^(n2 k1)
+//                                g_cols_inv  DIT over k1' -> r in natural order + the tile's partial
+//                                            argmax in 'full' order; g_final: reduce, 3 taps, parabola
+//                    HBM bytes per window: B*(8N + 3*16N) + P*(2*16N + 3*16N) = (56 B + 80 P) N, against
+//                    the 16 N P of the algorithmic model (cfg2: 408 N vs 48 N).
 // Twiddles: W_R^k tables per row length computed in double on the host; the large W_L^(a*b) factor of
 // the four-step is the product of two table entries (a*b mod L split into high and low digits).
 #pragma once
@@ -34,20 +39,27 @@ __device__ __forceinline__ float2 g_cmulc(float2 a, float2 b) {   // a * conj(b)
     return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
 }
 
-// In-place transforms of one row of R = 2^logR points held in LDS; tw[k] = W_R^k, k < R/2.  Two
-// radix-2 stages are fused per pass over the row (a radix-4 butterfly in registers: one LDS read and
-// write of the row and one barrier per TWO stages; an odd logR leaves one plain radix-2 stage); the
-// data flow, and with it the output order, is that of the radix-2 network.
+// In-place transforms of R = 2^logR points held in LDS; tw[k] = W_R^k, k < R/2.  Two radix-2 stages
+// are fused per pass (a radix-4 butterfly in registers: one LDS read and write and one barrier per
+// TWO stages; an odd logR leaves one plain radix-2 stage); the data flow, and with it the output
+// order, is that of the radix-2 network.  LOGT > 0: 2^LOGT interleaved transforms at once (element e
+// of transform c at x[(e << LOGT) | c]: a tile of columns of a row-major matrix; consecutive threads
+// take consecutive columns, so LDS accesses stay conflict free).
 // DIF: natural in -> bit-reversed out (forward, W = exp(-2 pi i / R)).
+template <int LOGT = 0>
 __device__ __forceinline__ void lds_dif(float2* x, int logR, const float2* __restrict__ tw, int tid, int nthr) {
+    constexpr int T = 1 << LOGT;
     int s = logR - 1;
     for (; s >= 1; s -= 2) {          // stages s (half = 2q) and s-1 (half = q)
         const int q = 1 << (s - 1);
-        const int quads = 1 << (logR - 2);
-        for (int i = tid; i < quads; i += nthr) {
+        const int work = (1 << (logR - 2)) << LOGT;
+        for (int idx = tid; idx < work; idx += nthr) {
+            const int c = idx & (T - 1), i = idx >> LOGT;
             const int l = i & (q - 1);
             const int j = ((i >> (s - 1)) << (s + 1)) | l;
-            const float2 x0 = x[j], x1 = x[j + q], x2 = x[j + 2 * q], x3 = x[j + 3 * q];
+            float2* p = x + ((long)j << LOGT) + c;
+            const int qs = q << LOGT;
+            const float2 x0 = p[0], x1 = p[qs], x2 = p[2 * qs], x3 = p[3 * qs];
             const float2 wa = tw[l << (logR - 1 - s)];          // stage s, element j
             const float2 wb = make_float2(wa.y, -wa.x);         // stage s, element j+q: wa * W_R^(R/4) = -i wa
             const float2 w2 = tw[l << (logR - s)];              // stage s-1
@@ -55,53 +67,62 @@ __device__ __forceinline__ void lds_dif(float2* x, int logR, const float2* __res
             const float2 a2 = g_cmul(make_float2(x0.x - x2.x, x0.y - x2.y), wa);
             const float2 a1 = make_float2(x1.x + x3.x, x1.y + x3.y);
             const float2 a3 = g_cmul(make_float2(x1.x - x3.x, x1.y - x3.y), wb);
-            x[j] = make_float2(a0.x + a1.x, a0.y + a1.y);
-            x[j + q] = g_cmul(make_float2(a0.x - a1.x, a0.y - a1.y), w2);
-            x[j + 2 * q] = make_float2(a2.x + a3.x, a2.y + a3.y);
-            x[j + 3 * q] = g_cmul(make_float2(a2.x - a3.x, a2.y - a3.y), w2);
+            p[0] = make_float2(a0.x + a1.x, a0.y + a1.y);
+            p[qs] = g_cmul(make_float2(a0.x - a1.x, a0.y - a1.y), w2);
+            p[2 * qs] = make_float2(a2.x + a3.x, a2.y + a3.y);
+            p[3 * qs] = g_cmul(make_float2(a2.x - a3.x, a2.y - a3.y), w2);
         }
         __syncthreads();
     }
     if (s == 0) {                     // odd logR: the last stage (half = 1, twiddle 1)
-        const int half_n = 1 << (logR - 1);
-        for (int i = tid; i < half_n; i += nthr) {
-            const float2 a = x[2 * i], b = x[2 * i + 1];
-            x[2 * i] = make_float2(a.x + b.x, a.y + b.y);
-            x[2 * i + 1] = make_float2(a.x - b.x, a.y - b.y);
+        const int work = (1 << (logR - 1)) << LOGT;
+        for (int idx = tid; idx < work; idx += nthr) {
+            const int c = idx & (T - 1), i = idx >> LOGT;
+            float2* p = x + ((long)(2 * i) << LOGT) + c;
+            const float2 a = p[0], b = p[T];
+            p[0] = make_float2(a.x + b.x, a.y + b.y);
+            p[T] = make_float2(a.x - b.x, a.y - b.y);
         }
         __syncthreads();
     }
 }
 // DIT with conjugated twiddles: bit-reversed in -> natural out (inverse, unnormalised).
+template <int LOGT = 0>
 __device__ __forceinline__ void lds_dit_inv(float2* x, int logR, const float2* __restrict__ tw, int tid, int nthr) {
+    constexpr int T = 1 << LOGT;
     int s = 0;
     if (logR & 1) {                   // odd logR: the first stage (half = 1, twiddle 1) on its own
-        const int half_n = 1 << (logR - 1);
-        for (int i = tid; i < half_n; i += nthr) {
-            const float2 a = x[2 * i], b = x[2 * i + 1];
-            x[2 * i] = make_float2(a.x + b.x, a.y + b.y);
-            x[2 * i + 1] = make_float2(a.x - b.x, a.y - b.y);
+        const int work = (1 << (logR - 1)) << LOGT;
+        for (int idx = tid; idx < work; idx += nthr) {
+            const int c = idx & (T - 1), i = idx >> LOGT;
+            float2* p = x + ((long)(2 * i) << LOGT) + c;
+            const float2 a = p[0], b = p[T];
+            p[0] = make_float2(a.x + b.x, a.y + b.y);
+            p[T] = make_float2(a.x - b.x, a.y - b.y);
         }
         __syncthreads();
         s = 1;
     }
     for (; s + 1 < logR; s += 2) {    // stages s (half = q) and s+1 (half = 2q)
         const int q = 1 << s;
-        const int quads = 1 << (logR - 2);
-        for (int i = tid; i < quads; i += nthr) {
+        const int work = (1 << (logR - 2)) << LOGT;
+        for (int idx = tid; idx < work; idx += nthr) {
+            const int c = idx & (T - 1), i = idx >> LOGT;
             const int l = i & (q - 1);
             const int j = ((i >> s) << (s + 2)) | l;
+            float2* p = x + ((long)j << LOGT) + c;
+            const int qs = q << LOGT;
             const float2 w1 = tw[l << (logR - 1 - s)];          // stage s
             const float2 wa = tw[l << (logR - 2 - s)];          // stage s+1, element j
             const float2 wb = make_float2(wa.y, -wa.x);         // stage s+1, element j+q: -i wa (conjugated below)
-            const float2 x0 = x[j], x1 = g_cmulc(x[j + q], w1), x2 = x[j + 2 * q], x3 = g_cmulc(x[j + 3 * q], w1);
+            const float2 x0 = p[0], x1 = g_cmulc(p[qs], w1), x2 = p[2 * qs], x3 = g_cmulc(p[3 * qs], w1);
             const float2 a0 = make_float2(x0.x + x1.x, x0.y + x1.y), a1 = make_float2(x0.x - x1.x, x0.y - x1.y);
             const float2 b0 = g_cmulc(make_float2(x2.x + x3.x, x2.y + x3.y), wa);
             const float2 b1 = g_cmulc(make_float2(x2.x - x3.x, x2.y - x3.y), wb);
-            x[j] = make_float2(a0.x + b0.x, a0.y + b0.y);
-            x[j + 2 * q] = make_float2(a0.x - b0.x, a0.y - b0.y);
-            x[j + q] = make_float2(a1.x + b1.x, a1.y + b1.y);
-            x[j + 3 * q] = make_float2(a1.x - b1.x, a1.y - b1.y);
+            p[0] = make_float2(a0.x + b0.x, a0.y + b0.y);
+            p[2 * qs] = make_float2(a0.x - b0.x, a0.y - b0.y);
+            p[qs] = make_float2(a1.x + b1.x, a1.y + b1.y);
+            p[3 * qs] = make_float2(a1.x - b1.x, a1.y - b1.y);
         }
         __syncthreads();
     }
@@ -210,18 +231,6 @@ __global__ __launch_bounds__(kGThreads) void g_pair_small(const float2* __restri
 }
 
 // ---- large path -------------------------------------------------------------------------------
-// batched tiled transpose: in [batch][rows][cols] -> out [batch][cols][rows]
-__global__ void g_transpose(const float2* __restrict__ in, float2* __restrict__ out, int rows, int cols) {
-    __shared__ float2 tile[32][33];
-    const long boff = (long)blockIdx.z * rows * cols;
-    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
-    for (int r = threadIdx.y; r < 32; r += 8)
-        tile[r][threadIdx.x] = in[boff + (long)(r0 + r) * cols + c0 + threadIdx.x];
-    __syncthreads();
-    for (int c = threadIdx.y; c < 32; c += 8)
-        out[boff + (long)(c0 + c) * rows + r0 + threadIdx.x] = tile[threadIdx.x][c];
-}
-
 __device__ __forceinline__ int brev(int v, int bits) { return (int)(__brev((unsigned)v) >> (32 - bits)); }
 
 // W_L^(m), m in [0, L): product of the two host tables (hi digit, lo digit)
@@ -295,18 +304,30 @@ __global__ __launch_bounds__(kGThreads) void g_rows(float2* __restrict__ data, c
     }
 }
 
-// zero-padded window as the [L1][L2] matrix, transposed on the fly: out[n2][n1] = x[n1*L2 + n2] (0 past N)
+// ---- column passes of the four-step (no transposes through HBM) ----------------------------------
+// The L-point sequence is the row-major matrix [L1][L2], n = n1*L2 + n2.  A workgroup takes a tile of
+// kColT = 16 adjacent columns (128-byte row segments: full cache lines) with all L1 rows into LDS
+// ([L1][16], up to 128 KiB of the CU's 160 KiB), transforms the 16 columns there and writes the tile
+// back in place of a transpose + row pass + transpose.
+constexpr int kColLogT = 4, kColT = 1 << kColLogT;
+// forward: zero-padded window -> out[k1'][n2] = W_L^(n2*k1) * sum_n1 x[n1][n2] W_L1^(n1*k1)
+//   (k1' = bit-reversed k1).  grid (L2/16, items); only the rows n1 < L1/2 are non-zero and read.
 template <bool U8>
-__global__ void g_load_transposed(const void* __restrict__ iq, float2* __restrict__ out, int N, int L1, int L2,
-                                  long first_item) {
-    __shared__ float2 tile[32][33];
-    const long item = first_item + blockIdx.z;
-    const long ooff = (long)blockIdx.z * L1 * L2;
-    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;   // in: rows n1, cols n2
-    for (int r = threadIdx.y; r < 32; r += 8) {
-        const long n = (long)(r0 + r) * L2 + c0 + threadIdx.x;
+__global__ __launch_bounds__(1024) void g_cols_fwd(const void* __restrict__ iq, float2* __restrict__ out,
+                                                   const float2* __restrict__ tw, int l1, int l2, long first_item,
+                                                   int lo_bits, const float2* __restrict__ thi,
+                                                   const float2* __restrict__ tlo) {
+    extern __shared__ __attribute__((aligned(16))) char gsm[];
+    float2* x = reinterpret_cast<float2*>(gsm);
+    const int L1 = 1 << l1, L2 = 1 << l2, tid = threadIdx.x, nthr = blockDim.x;
+    const long L = (long)L1 << l2, N = L >> 1;
+    const int c0 = blockIdx.x * kColT;
+    const long item = first_item + blockIdx.y;
+    for (int idx = tid; idx < (L1 << kColLogT); idx += nthr) {
+        const int c = idx & (kColT - 1), n1 = idx >> kColLogT;
         float2 v = make_float2(0.f, 0.f);
-        if (n < N) {
+        if (n1 < (L1 >> 1)) {
+            const long n = (long)n1 * L2 + c0 + c;
             if constexpr (U8) {
                 const uchar2 b = reinterpret_cast<const uchar2*>(iq)[item * N + n];
                 v = make_float2((float)b.x - 127.5f, (float)b.y - 127.5f);
@@ -314,43 +335,67 @@ __global__ void g_load_transposed(const void* __restrict__ iq, float2* __restric
                 v = reinterpret_cast<const float2*>(iq)[item * N + n];
             }
         }
-        tile[r][threadIdx.x] = v;
+        x[idx] = v;
     }
     __syncthreads();
-    for (int c = threadIdx.y; c < 32; c += 8)
-        out[ooff + (long)(c0 + c) * L1 + r0 + threadIdx.x] = tile[threadIdx.x][c];
+    lds_dif<kColLogT>(x, l1, tw, tid, nthr);
+    // per-column twiddle tables: W_L^(n2*e) = T1[e & (2^a-1)] * T2[e >> a]   (n2*e < L: no reduction)
+    const int a = l1 >> 1, na = 1 << a, nb = L1 >> a;
+    float2* tab = x + ((long)L1 << kColLogT);               // [16][na + nb]
+    for (int idx = tid; idx < kColT * (na + nb); idx += nthr) {
+        const int c = idx / (na + nb), e = idx % (na + nb);
+        const long ee = e < na ? (long)e : ((long)(e - na) << a);
+        tab[idx] = big_tw((long)(c0 + c) * ee, lo_bits, thi, tlo);
+    }
+    __syncthreads();
+    float2* o = out + (long)blockIdx.y * L;
+    for (int idx = tid; idx < (L1 << kColLogT); idx += nthr) {
+        const int c = idx & (kColT - 1), pos = idx >> kColLogT;
+        const int k1 = brev(pos, l1);
+        const float2* tc = tab + c * (na + nb);
+        const float2 w = g_cmul(tc[k1 & (na - 1)], tc[na + (k1 >> a)]);
+        o[(long)pos * L2 + c0 + c] = g_cmul(x[idx], w);
+    }
 }
-
-// partial argmax of |r|^2 in 'full' order: grid (parts, slots).  r is the inverse transform as the
-// last row pass leaves it, [n2][n1] (position p = n2*L1 + n1 holds circular index m = n1*L2 + n2):
-// reading it in place saves the transpose back to natural order (l1 = 0 means natural order).
-__device__ __forceinline__ long nat_to_pos(long m, int l1, int l2) {
-    return l1 == 0 ? m : ((m & ((1L << l2) - 1)) << l1) | (m >> l2);
-}
-__global__ __launch_bounds__(kGThreads) void g_absmax(const float2* __restrict__ r, int N, int l1, int l2,
-                                                      float* __restrict__ pv, int* __restrict__ pk) {
-    __shared__ float sv[kGThreads];
-    __shared__ int sk[kGThreads];
-    const long L = 2L * N;
-    const float2* x = r + (long)blockIdx.y * L;
+// inverse: in[k1'][n2] (after the inverse row pass and its twiddle) -> r[n1][n2] natural order, plus this
+// tile's partial argmax of |r|^2 in 'full' order.  grid (L2/16, slots); parts = L2/16.
+__global__ __launch_bounds__(1024) void g_cols_inv(const float2* __restrict__ in, float2* __restrict__ out,
+                                                   const float2* __restrict__ tw, int l1, int l2,
+                                                   float* __restrict__ pv, int* __restrict__ pk) {
+    extern __shared__ __attribute__((aligned(16))) char gsm[];
+    float2* x = reinterpret_cast<float2*>(gsm);
+    const int L1 = 1 << l1, L2 = 1 << l2, tid = threadIdx.x, nthr = blockDim.x;
+    const long L = (long)L1 << l2;
+    const int N = (int)(L >> 1);
+    const int c0 = blockIdx.x * kColT;
+    const float2* src = in + (long)blockIdx.y * L;
+    for (int idx = tid; idx < (L1 << kColLogT); idx += nthr)
+        x[idx] = src[(long)(idx >> kColLogT) * L2 + c0 + (idx & (kColT - 1))];
+    __syncthreads();
+    lds_dit_inv<kColLogT>(x, l1, tw, tid, nthr);
+    float2* o = out + (long)blockIdx.y * L;
     float best = -1.0f;
     int bk = 0x7fffffff;
-    for (long p = (long)blockIdx.x * kGThreads + threadIdx.x; p < L; p += (long)gridDim.x * kGThreads) {
-        const long m = l1 == 0 ? p : ((p & ((1L << l1) - 1)) << l2) | (p >> l1);
+    for (int idx = tid; idx < (L1 << kColLogT); idx += nthr) {
+        const long m = (long)(idx >> kColLogT) * L2 + c0 + (idx & (kColT - 1));
+        const float2 e = x[idx];
+        o[m] = e;
         const int k = full_index((int)m, N);
-        if (k < 0) continue;
-        const float2 e = x[p];
         const float v = e.x * e.x + e.y * e.y;
-        if (v > best || (v == best && k < bk)) { best = v; bk = k; }
+        if (k >= 0 && (v > best || (v == best && k < bk))) { best = v; bk = k; }
     }
-    block_argmax(best, bk, sv, sk, threadIdx.x, kGThreads);
-    if (threadIdx.x == 0) {
+    __syncthreads();                                            // x is reused as the reduction scratch
+    float* sv = reinterpret_cast<float*>(gsm);
+    int* sk = reinterpret_cast<int*>(sv + nthr);
+    block_argmax(best, bk, sv, sk, tid, nthr);
+    if (tid == 0) {
         pv[(long)blockIdx.y * gridDim.x + blockIdx.x] = best;
         pk[(long)blockIdx.y * gridDim.x + blockIdx.x] = bk;
     }
 }
 
-__global__ void g_final(const float2* __restrict__ r, int N, int l1, int l2, const float* __restrict__ pv,
+// final reduction over a slot's partial maxima (one per column tile), 3 taps from r (natural order), parabola
+__global__ void g_final(const float2* __restrict__ r, int N, const float* __restrict__ pv,
                         const int* __restrict__ pk, int parts, int n_slots, long out_base, float out_scale,
                         int* __restrict__ lag_int, float* __restrict__ lag_frac, float* __restrict__ peak) {
     const int slot = blockIdx.x * blockDim.x + threadIdx.x;
@@ -366,7 +411,7 @@ __global__ void g_final(const float2* __restrict__ r, int N, int l1, int l2, con
     const float b = sqrtf(best) * out_scale;
     float frac = 0.0f;
     if (bk > 0 && bk < 2 * N - 2) {
-        const float2 ra = x[nat_to_pos(circ_index(bk - 1, N), l1, l2)], rc = x[nat_to_pos(circ_index(bk + 1, N), l1, l2)];
+        const float2 ra = x[circ_index(bk - 1, N)], rc = x[circ_index(bk + 1, N)];
         frac = parabola(sqrtf(ra.x * ra.x + ra.y * ra.y) * out_scale, b, sqrtf(rc.x * rc.x + rc.y * rc.y) * out_scale);
     }
     lag_int[out_base + slot] = bk - (N - 1);

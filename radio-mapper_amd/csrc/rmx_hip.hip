@@ -1297,6 +1297,23 @@ static int upload(rmx_ctx* c, float2** dst, const std::vector<float2>& v) {
     return RMX_OK;
 }
 
+// dynamic LDS of the four-step kernels
+static size_t gen_rows_lds(int R) {                     // rows + per-row twiddle tables (TW passes)
+    const int tpr = (R >> 2) < gen::kGThreads ? ((R >> 2) > 0 ? (R >> 2) : 1) : gen::kGThreads;
+    int logR = 0;
+    while ((1 << logR) < R) ++logR;
+    const int a = logR >> 1;
+    return (size_t)(gen::kGThreads / tpr) * ((size_t)R + (1 << a) + (R >> a)) * 8;
+}
+static size_t gen_cols_lds(int l1) {                    // [L1][16] tile + 16 per-column twiddle tables
+    const int a = l1 >> 1;
+    return ((size_t)(1 << l1) * gen::kColT + (size_t)gen::kColT * ((1 << a) + ((1 << l1) >> a))) * 8;
+}
+static int gen_cols_threads(int l1) {                   // one radix-4 work item per thread and pass, <= 1024
+    const long work = ((long)1 << l1) * gen::kColT / 4;
+    return work >= 1024 ? 1024 : (work < 64 ? 64 : (int)work);
+}
+
 static int generic_init(rmx_ctx* c) {
     using namespace gen;
     c->generic = true;
@@ -1313,7 +1330,8 @@ static int generic_init(rmx_ctx* c) {
         RMX_HIP(c, hipFuncSetAttribute((const void*)g_pair_small, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)(L * 8 + kGThreads * 8)));
     } else {
-        c->g_logL1 = (c->g_logL + 1) / 2;
+        // columns of length L1 <= 1024 (a tile of 16 columns is L1*128 bytes of LDS), rows of L2 = L/L1 <= 8192
+        c->g_logL1 = c->g_logL / 2 < 10 ? c->g_logL / 2 : 10;
         c->g_logL2 = c->g_logL - c->g_logL1;
         c->g_lo_bits = (c->g_logL + 1) / 2;
         make_row_table(t, 1 << c->g_logL1);
@@ -1328,6 +1346,12 @@ static int generic_init(rmx_ctx* c) {
         if (rc) return rc;
         rc = upload(c, &c->g_tlo, tlo);
         if (rc) return rc;
+        const int cols_lds = (int)gen_cols_lds(c->g_logL1), rows_lds = (int)gen_rows_lds(1 << c->g_logL2);
+        RMX_HIP(c, hipFuncSetAttribute((const void*)g_cols_fwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, cols_lds));
+        RMX_HIP(c, hipFuncSetAttribute((const void*)g_cols_fwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, cols_lds));
+        RMX_HIP(c, hipFuncSetAttribute((const void*)g_cols_inv, hipFuncAttributeMaxDynamicSharedMemorySize, cols_lds));
+        RMX_HIP(c, hipFuncSetAttribute((const void*)(g_rows<true, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, rows_lds));
+        RMX_HIP(c, hipFuncSetAttribute((const void*)(g_rows<false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, rows_lds));
     }
     // windows per chunk: spectra (B*L) + products (P*L) + work buffer, 8 bytes each, under ~3 GiB
     const long per_win = (long)(c->n_buoys + 2L * (all_pairs > c->n_buoys ? all_pairs : c->n_buoys)) * L * 8;
@@ -1358,8 +1382,9 @@ static int generic_ensure(rmx_ctx* c, int n_pairs) {
             const long big = items > slots ? items : slots;
             RMX_HIP(c, hipMalloc((void**)&c->g_prod, slots * L * 8));
             RMX_HIP(c, hipMalloc((void**)&c->g_tmp, big * L * 8));
-            RMX_HIP(c, hipMalloc((void**)&c->g_pv, slots * 64 * sizeof(float)));
-            RMX_HIP(c, hipMalloc((void**)&c->g_pk, slots * 64 * sizeof(int)));
+            const long parts = (1L << c->g_logL2) / kColT;       // one partial argmax per column tile
+            RMX_HIP(c, hipMalloc((void**)&c->g_pv, slots * parts * sizeof(float)));
+            RMX_HIP(c, hipMalloc((void**)&c->g_pk, slots * parts * sizeof(int)));
             c->g_slots_alloc = slots;
         }
     }
@@ -1401,41 +1426,30 @@ static int generic_batch(rmx_ctx* c, const void* d_iq, int n_windows, int n_pair
             continue;
         }
         const int l1 = c->g_logL1, l2 = c->g_logL2, L1 = 1 << l1, L2 = 1 << l2;
-        const dim3 tb(32, 8);
-        // forward: T (fused into the load), rows(L1) * W_L^(n2 k1), T, rows(L2)
-        if (u8)
-            hipLaunchKernelGGL(g_load_transposed<true>, dim3(L2 / 32, L1 / 32, items), tb, 0, st, d_iq, c->g_tmp, N, L1, L2,
-                               first_item);
-        else
-            hipLaunchKernelGGL(g_load_transposed<false>, dim3(L2 / 32, L1 / 32, items), tb, 0, st, d_iq, c->g_tmp, N, L1, L2,
-                               first_item);
         auto rows_grid = [](long rows, int R) -> dim3 {      // workgroups for `rows` rows of length R
             const int tpr = (R >> 2) < kGThreads ? ((R >> 2) > 0 ? (R >> 2) : 1) : kGThreads;
             const int rpw = kGThreads / tpr;
             return dim3((unsigned)((rows + rpw - 1) / rpw));
         };
-        auto rows_lds = [](int R) -> size_t {               // rows + per-row twiddle tables (TW passes)
-            const int tpr = (R >> 2) < kGThreads ? ((R >> 2) > 0 ? (R >> 2) : 1) : kGThreads;
-            int logR = 0;
-            while ((1 << logR) < R) ++logR;
-            const int a = logR >> 1;
-            return (size_t)(kGThreads / tpr) * ((size_t)R + (1 << a) + (R >> a)) * 8;
-        };
-        hipLaunchKernelGGL((g_rows<true, true>), rows_grid((long)items * L2, L1), dim3(kGThreads), rows_lds(L1), st, c->g_tmp,
-                           c->g_tw1, l1, L2, l2, L, c->g_lo_bits, c->g_thi, c->g_tlo, 1.0f, (long)items * L2);
-        hipLaunchKernelGGL(g_transpose, dim3(L1 / 32, L2 / 32, items), tb, 0, st, c->g_tmp, c->g_spec, L2, L1);
-        hipLaunchKernelGGL((g_rows<true, false>), rows_grid((long)items * L1, L2), dim3(kGThreads), rows_lds(L2), st, c->g_spec,
+        const int cthr = gen_cols_threads(l1);
+        const size_t clds = gen_cols_lds(l1), rlds = gen_rows_lds(L2);
+        // forward: column pass (zero-padded window -> [k1'][n2] * W_L^(n2 k1)), row pass (-> [k1'][k2'])
+        if (u8)
+            hipLaunchKernelGGL(g_cols_fwd<true>, dim3(L2 / kColT, items), dim3(cthr), clds, st, d_iq, c->g_spec, c->g_tw1, l1, l2,
+                               first_item, c->g_lo_bits, c->g_thi, c->g_tlo);
+        else
+            hipLaunchKernelGGL(g_cols_fwd<false>, dim3(L2 / kColT, items), dim3(cthr), clds, st, d_iq, c->g_spec, c->g_tw1, l1, l2,
+                               first_item, c->g_lo_bits, c->g_thi, c->g_tlo);
+        hipLaunchKernelGGL((g_rows<true, false, false>), rows_grid((long)items * L1, L2), dim3(kGThreads), rlds, st, c->g_spec,
                            c->g_tw2, l2, L1, l1, L, c->g_lo_bits, c->g_thi, c->g_tlo, fwd_scale, (long)items * L1);
-        // pairs: [product on load] rows(L2)^-1 * conj W_L^(n2 k1), T, rows(L1)^-1; argmax on the [n2][n1] result
-        hipLaunchKernelGGL((g_rows<false, true, true>), rows_grid((long)slots * L1, L2), dim3(kGThreads), rows_lds(L2), st,
+        // pairs: row pass ([product on load] rows(L2)^-1 * conj W_L^(n2 k1)), column pass (-> r natural + partial argmax)
+        hipLaunchKernelGGL((g_rows<false, true, true>), rows_grid((long)slots * L1, L2), dim3(kGThreads), rlds, st,
                            c->g_prod, c->g_tw2, l2, L1, l1, L, c->g_lo_bits, c->g_thi, c->g_tlo, 1.0f, (long)slots * L1,
                            c->g_spec, c->g_pairs, n_pairs, B);
-        hipLaunchKernelGGL(g_transpose, dim3(L2 / 32, L1 / 32, slots), tb, 0, st, c->g_prod, c->g_tmp, L1, L2);
-        hipLaunchKernelGGL((g_rows<false, false>), rows_grid((long)slots * L2, L1), dim3(kGThreads), rows_lds(L1), st, c->g_tmp,
-                           c->g_tw1, l1, L2, l2, L, c->g_lo_bits, c->g_thi, c->g_tlo, 1.0f, (long)slots * L2);
-        hipLaunchKernelGGL(g_absmax, dim3(64, slots), dim3(kGThreads), 0, st, c->g_tmp, N, l1, l2, c->g_pv, c->g_pk);
-        hipLaunchKernelGGL(g_final, dim3((slots + 63) / 64), dim3(64), 0, st, c->g_tmp, N, l1, l2, c->g_pv, c->g_pk, 64, slots,
-                           (long)w0 * n_pairs, out_scale, d_lag, d_frac, d_peak);
+        hipLaunchKernelGGL(g_cols_inv, dim3(L2 / kColT, slots), dim3(cthr), clds, st, c->g_prod, c->g_tmp, c->g_tw1, l1, l2,
+                           c->g_pv, c->g_pk);
+        hipLaunchKernelGGL(g_final, dim3((slots + 63) / 64), dim3(64), 0, st, c->g_tmp, N, c->g_pv, c->g_pk, L2 / kColT,
+                           slots, (long)w0 * n_pairs, out_scale, d_lag, d_frac, d_peak);
         RMX_HIP(c, hipGetLastError());
     }
     return RMX_OK;
