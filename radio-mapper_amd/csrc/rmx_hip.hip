@@ -1162,6 +1162,9 @@ struct rmx_ctx {
     long g_slots_alloc = 0;
     int g_pairs_n = -1;
     std::vector<int32_t> g_pairs_plan;
+    // host-pointer input of the fused path: copies pipelined against the kernels on a second stream
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t copy_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     // rmx_solve_batch work buffers
     double* sv_buoys = nullptr;  int* sv_pairs = nullptr;  size_t sv_pairs_cap = 0;
     void* sv_in = nullptr;  size_t sv_in_bytes = 0;  void* sv_out = nullptr;  size_t sv_out_bytes = 0;
@@ -1459,6 +1462,8 @@ static int generic_batch(rmx_ctx* c, const void* d_iq, int n_windows, int n_pair
 
 using namespace rmx;
 
+static constexpr int kHostSubChunk = 512;   // windows per copy/kernel step of the pipelined host-pointer path
+
 extern "C" {
 
 int rmx_version(void) { return RMX_VERSION; }
@@ -1550,6 +1555,9 @@ void rmx_destroy(rmx_ctx* c) {
     for (void* p : {(void*)c->g_tw, (void*)c->g_tw1, (void*)c->g_tw2, (void*)c->g_thi, (void*)c->g_tlo, (void*)c->g_spec,
                     (void*)c->g_tmp, (void*)c->g_prod, (void*)c->g_pv, (void*)c->g_pk, (void*)c->g_pairs})
         if (p) (void)hipFree(p);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    for (hipEvent_t e : c->copy_ev)
+        if (e) (void)hipEventDestroy(e);
     for (void* p : {(void*)c->sv_buoys, (void*)c->sv_pairs, c->sv_in, c->sv_out})
         if (p) (void)hipFree(p);
     if (c->caf_child) rmx_destroy(c->caf_child);
@@ -1647,6 +1655,7 @@ int rmx_xcorr_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pa
     const size_t samp_bytes = u8 ? 2 : 8;
     const size_t in_bytes = (size_t)n_windows * c->n_buoys * c->n_samples * samp_bytes;
     const void* d_iq = iq;
+    bool pipelined = false;
     if (!in_dev) {
         if (c->d_in_bytes < in_bytes) {
             if (c->d_in) (void)hipFree(c->d_in);
@@ -1655,7 +1664,19 @@ int rmx_xcorr_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pa
             RMX_HIP(c, hipMalloc(&c->d_in, in_bytes));
             c->d_in_bytes = in_bytes;
         }
-        RMX_HIP(c, hipMemcpyAsync(c->d_in, iq, in_bytes, hipMemcpyHostToDevice, c->stream));
+        // fused path: the copy is cut into sub-chunks issued on a second stream, each followed by its
+        // kernel launch, so that copy k+1 travels while kernel k runs (below); otherwise one copy up front
+        pipelined = !c->generic && c->fused && c->plan_all_pairs && n_windows > kHostSubChunk;
+        if (pipelined) {
+            if (!c->copy_stream) RMX_HIP(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+            for (hipEvent_t& e : c->copy_ev)
+                if (!e) RMX_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            // earlier work of this ctx may still read the staging buffer
+            RMX_HIP(c, hipEventRecord(c->copy_ev[3], c->stream));
+            RMX_HIP(c, hipStreamWaitEvent(c->copy_stream, c->copy_ev[3], 0));
+        } else {
+            RMX_HIP(c, hipMemcpyAsync(c->d_in, iq, in_bytes, hipMemcpyHostToDevice, c->stream));
+        }
         d_iq = c->d_in;
     }
     int* d_lag = lag_int;
@@ -1699,28 +1720,45 @@ int rmx_xcorr_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pa
     c->ev_used = 0;
     c->ev_kind.clear();
     if (c->timing) {
-        rc = ensure_events(c, (size_t)n_chunks * 4);
+        const size_t subs = pipelined ? (size_t)(n_windows + kHostSubChunk - 1) / kHostSubChunk + n_chunks : n_chunks;
+        rc = ensure_events(c, subs * 4);
         if (rc != RMX_OK) return rc;
     }
+    int n_sub = 0;
     for (int w0 = 0; w0 < n_windows; w0 += c->chunk_windows) {
         const int wc = (n_windows - w0 < c->chunk_windows) ? n_windows - w0 : c->chunk_windows;
         if (c->fused && c->plan_all_pairs) {
-            // one persistent workgroup per CU (the kernel's LDS footprint allows exactly one)
-            const int wgrid = wc < c->n_cus ? wc : c->n_cus;
-            if (c->timing) RMX_HIP(c, hipEventRecord(c->ev[c->ev_used], c->stream));
-            if (u8)
-                hipLaunchKernelGGL(k_win<true>, dim3(wgrid), dim3(kThreads), kLdsWinBytes, c->stream, d_iq, c->d_spec,
-                                   c->d_tw1, c->d_tw2, c->n_buoys, (long)w0, fwd_scale, out_scale, d_lag, d_frac,
-                                   d_peak, wc, c->dbg);
-            else
-                hipLaunchKernelGGL(k_win<false>, dim3(wgrid), dim3(kThreads), kLdsWinBytes, c->stream, d_iq, c->d_spec,
-                                   c->d_tw1, c->d_tw2, c->n_buoys, (long)w0, fwd_scale, out_scale, d_lag, d_frac,
-                                   d_peak, wc, c->dbg);
-            RMX_HIP(c, hipGetLastError());
-            if (c->timing) {
-                RMX_HIP(c, hipEventRecord(c->ev[c->ev_used + 1], c->stream));
-                c->ev_used += 2;
-                c->ev_kind.push_back(1);
+            const int sub = pipelined ? kHostSubChunk : wc;
+            for (int s0 = 0; s0 < wc; s0 += sub) {
+                const int sc = wc - s0 < sub ? wc - s0 : sub;
+                const long wfirst = (long)w0 + s0;
+                if (pipelined) {
+                    const size_t off = (size_t)wfirst * c->n_buoys * c->n_samples * samp_bytes;
+                    const size_t nb = (size_t)sc * c->n_buoys * c->n_samples * samp_bytes;
+                    hipEvent_t ev = c->copy_ev[n_sub % 3];
+                    ++n_sub;
+                    RMX_HIP(c, hipMemcpyAsync((char*)c->d_in + off, (const char*)iq + off, nb, hipMemcpyHostToDevice,
+                                              c->copy_stream));
+                    RMX_HIP(c, hipEventRecord(ev, c->copy_stream));
+                    RMX_HIP(c, hipStreamWaitEvent(c->stream, ev, 0));
+                }
+                // one persistent workgroup per CU (the kernel's LDS footprint allows exactly one)
+                const int wgrid = sc < c->n_cus ? sc : c->n_cus;
+                if (c->timing) RMX_HIP(c, hipEventRecord(c->ev[c->ev_used], c->stream));
+                if (u8)
+                    hipLaunchKernelGGL(k_win<true>, dim3(wgrid), dim3(kThreads), kLdsWinBytes, c->stream, d_iq, c->d_spec,
+                                       c->d_tw1, c->d_tw2, c->n_buoys, wfirst, fwd_scale, out_scale, d_lag, d_frac,
+                                       d_peak, sc, c->dbg);
+                else
+                    hipLaunchKernelGGL(k_win<false>, dim3(wgrid), dim3(kThreads), kLdsWinBytes, c->stream, d_iq, c->d_spec,
+                                       c->d_tw1, c->d_tw2, c->n_buoys, wfirst, fwd_scale, out_scale, d_lag, d_frac,
+                                       d_peak, sc, c->dbg);
+                RMX_HIP(c, hipGetLastError());
+                if (c->timing) {
+                    RMX_HIP(c, hipEventRecord(c->ev[c->ev_used + 1], c->stream));
+                    c->ev_used += 2;
+                    c->ev_kind.push_back(1);
+                }
             }
             continue;
         }
