@@ -164,12 +164,19 @@ def main():
     sync_all()
     fwd_ms = pair_ms = 0.0
     fwd_n = pair_n = 0
+    # HIP events on the launch stream (the ctx uses torch's current stream) around the timed region:
+    # the sustained, back-to-back launch duration (isolated launches run at a higher clock)
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record(stream)
     for _ in range(args.steps):
         step()
         # (rmx_last_timing would synchronise; it is read once per step only after the loop below)
+    ev1.record(stream)
     sync_all()
     elapsed = time.perf_counter() - t0
+    region_ms = ev0.elapsed_time(ev1)
     # kernel durations from the HIP events bracketing every launch on the launch stream: the last
     # step of the timed region, then the same step repeated with a read-back after each
     n_meas = max(min(args.steps, 10), 1)
@@ -198,7 +205,19 @@ def main():
 
     # host-side gather of the lag scalars (the only exchange of the multi-GPU path)
     li, lf, pk = lag.cpu().numpy(), frac.cpu().numpy(), peak.cpu().numpy()
-    gathered = gather_lags(li, lf, pk) if world > 1 else (li, lf, pk)
+    if world > 1 and backend == "nccl":
+        # every rank holds the same number of windows: plain all_gather of the three result tensors
+        # (12 bytes per pair-window; outside the timed region)
+        outs = []
+        for tns in (lag, frac, peak):
+            bucket = [torch.empty_like(tns) for _ in range(world)]
+            dist.all_gather(bucket, tns)
+            outs.append(torch.cat(bucket, dim=0).cpu().numpy() if rank == 0 else None)
+        gathered = tuple(outs) if rank == 0 else None
+    else:
+        gathered = gather_lags(li, lf, pk) if world > 1 else (li, lf, pk)
+    if rank == 0:
+        assert gathered[0].shape == (W_total, P)
 
     # parity in the same run (rank 0, 32 windows) + cpu baseline
     parity = None
@@ -220,8 +239,10 @@ def main():
         units_per_step = W_total * P * N                      # IQ samples cross-correlated per step
         value = units_per_step / (ms_per_step * 1e-3)
         alg_bytes_per_pw = 16 * N + 12
-        pair_launch_ms = pair_ms / max(pair_n, 1)
+        isolated_launch_ms = pair_ms / max(pair_n, 1)
         launches_per_step = max(pair_n / n_meas, 1.0)
+        # average duration of the dominant kernel's launches inside the timed region
+        pair_launch_ms = region_ms / (args.steps * launches_per_step) if fwd_n == 0 else isolated_launch_ms
         windows_per_launch = W / launches_per_step
         alg_bytes_per_launch = windows_per_launch * P * alg_bytes_per_pw
         achieved = alg_bytes_per_launch / (pair_launch_ms * 1e-3) / 1e9 if pair_launch_ms > 0 else 0.0
@@ -244,7 +265,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_win (fused forward + pair kernel)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "alg_bytes_per_launch": alg_bytes_per_launch,
-                         "launch_ms": pair_launch_ms,
+                         "launch_ms": pair_launch_ms, "isolated_launch_ms": isolated_launch_ms,
                          "fwd_kernel_ms_per_step": fwd_ms / n_meas,
                          "pair_kernel_ms_per_step": pair_ms / n_meas,
                          "whole_path_frac": (W * P * alg_bytes_per_pw) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
