@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
-"""GPU box: rmx_solve_batch throughput (device arrays in and out) beside the CPU oracle.
-usage: bench_solve.py [B] [W]"""
+"""GPU box: rmx_solve_batch throughput (device arrays in and out) beside the CPU oracle (kept under
+tests/ because it imports the oracle; not collected by pytest).
+usage: python tests/perf_solve.py [B] [W]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))  # noqa: E702
 import ctypes as C
 import numpy as np
 import torch
