@@ -587,7 +587,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
                                                      int* __restrict__ lag_int, float* __restrict__ lag_frac,
                                                      float* __restrict__ peak, int n_win, int dbg_rt) {
 #ifdef RMX_ABLATE
-    const int dbg = dbg_rt;   // timing-only ablation build (wrong results): tools/gpu_probe.py
+    const int dbg = dbg_rt;   // timing-only ablation build (wrong results): tools/ablate.sh, tools/ablate_run.py
 #else
     constexpr int dbg = 0;
     (void)dbg_rt;
