@@ -94,8 +94,8 @@ def cpu_baseline(iq_sample, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--windows", type=int, default=4096, help="windows per GPU (cfg3: 4096)")
     ap.add_argument("--buoys", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")

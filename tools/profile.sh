@@ -7,7 +7,7 @@ tag=${1:-r01}
 out=$PWD/gpurun_out/prof_$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
-BENCH="python3 $PWD/bench.py --steps 20 --warmup 5 --no-cpu-baseline"
+BENCH="python3 $PWD/bench.py --steps 100 --warmup 20 --no-cpu-baseline"
 cd /tmp
 rocprofv3 --kernel-trace --stats -T -f csv -d "$out/stats" -o stats -- $BENCH > "$out/stats.log" 2>&1 || echo "stats run failed"
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_ACTIVE_INST_VALU" \
