@@ -855,9 +855,12 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
         int ts, qs;
         k_to_owner(kw, ts, qs);
         const int ls = ts & 63;
-        float sel = mag[0];
-#pragma unroll
-        for (int q = 1; q < 16; ++q) sel = (q == qs) ? mag[q] : sel;
+        // qs is wave-uniform (it comes out of the wave reductions): one indexed register read
+        // (s_set_gpr_idx) instead of a 16-way select chain
+        typedef float f16v __attribute__((ext_vector_type(16)));
+        const f16v mv = {mag[0], mag[1], mag[2],  mag[3],  mag[4],  mag[5],  mag[6],  mag[7],
+                         mag[8], mag[9], mag[10], mag[11], mag[12], mag[13], mag[14], mag[15]};
+        const float sel = mv[__builtin_amdgcn_readfirstlane(qs)];
         const int seli = __builtin_bit_cast(int, sel);
         const float tapm = ls >= 2 ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(seli, ls >= 2 ? ls - 2 : 0)) : -2.0f;
         const float tapp = ls <= 61 ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(seli, ls <= 61 ? ls + 2 : 63)) : -2.0f;
