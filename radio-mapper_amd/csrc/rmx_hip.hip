@@ -734,7 +734,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
             __builtin_amdgcn_raw_buffer_store_b128(w, ss, soff + (b * 8 + j) * (kThreads * 16), 0, 0);
         }
     };
-    // forward spectrum of the samples in x, in place (scaled by fwd_scale)
+    // forward spectrum of the samples in x, in place (carries the 2^-6 of the TW1 table)
     auto fwd = [&](C16& xc) __attribute__((always_inline)) {
         float2* img = (seq & 1) ? img1 : img0;
         float2 x[16];
@@ -754,7 +754,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
         }
         dft16_tw_row(x, tw2row);   // W_256^(n0*k1) as pre-twiddle of the last pass
 #pragma unroll
-        for (int q = 0; q < 16; ++q) xc.set(q, x[q].x * fwd_scale, x[q].y * fwd_scale);
+        for (int q = 0; q < 16; ++q) xc.set(q, x[q].x, x[q].y);   // (scaled by 2^-6 through the TW1 table)
         ++seq;
     };
     // One pair = two halves around its only workgroup barrier.
@@ -1213,6 +1213,8 @@ static int fail(rmx_ctx* c, int code, const char* fmt, ...) {
 
 static bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
 
+static constexpr int kTw1ScaleLog2 = 6;                       // spectra carry 2^-6 (L = 2^13: sqrt(L) rounded down)
+static constexpr double kTw1Scale = 1.0 / (1 << kTw1ScaleLog2);
 static void build_tables(std::vector<float4>& tw1, std::vector<float2>& tw2) {
     const double two_pi = 6.283185307179586476925286766559;
     tw1.resize(8 * kThreads);
@@ -1223,7 +1225,9 @@ static void build_tables(std::vector<float4>& tw1, std::vector<float2>& tw2) {
             // W_M^(u*k0) * (p ? W_L^u : 1), W_n = exp(-2*pi*i/n)
             double ang = -two_pi * (double)((u * k0) % kM) / (double)kM;
             if (p) ang += -two_pi * (double)u / (double)kL;
-            t1[k0 * kThreads + t] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+            // the power-of-two scale of the forward spectra rides on this table (exact): the forward
+            // transform multiplies by it once, the inverse once more (undone in out_scale)
+            t1[k0 * kThreads + t] = make_float2((float)(std::cos(ang) * kTw1Scale), (float)(std::sin(ang) * kTw1Scale));
         }
     }
     for (int j = 0; j < 8; ++j)
@@ -1711,12 +1715,12 @@ int rmx_xcorr_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pa
         }
         return RMX_OK;
     }
-    // power-of-two scaling: spectra carry 2^-hs, the product 2^-2hs, the taps the remaining factor
+    // power-of-two scaling: the TW1 table carries 2^-6, so the spectra carry 2^-6, the product 2^-12 and
+    // the inverse transform (which uses the table once more) 2^-18; the taps get the remaining factor
     int logl = 0;
     while ((1 << logl) < kL) ++logl;
-    const int hs = logl / 2;
-    const float fwd_scale = std::ldexp(1.0f, -hs);
-    const float out_scale = std::ldexp(1.0f, -(logl - 2 * hs));
+    const float fwd_scale = 1.0f;
+    const float out_scale = std::ldexp(1.0f, 3 * kTw1ScaleLog2 - logl);
 
     const int n_parts = c->plan_n_parts;
     const int n_chunks = (n_windows + c->chunk_windows - 1) / c->chunk_windows;
