@@ -234,6 +234,20 @@ __device__ __forceinline__ void cmul_inplace(float& x, float& y, float wr, float
                  : "s"(wr), "s"(wi));
 }
 
+// Four of them in ONE asm statement (hipcc puts an s_nop between consecutive asm statements):
+// (x_k + i y_k) *= (wr_k + i wi_k), k = 0..3.
+__device__ __forceinline__ void cmul4_inplace(float& x0, float& y0, float& x1, float& y1, float& x2, float& y2,
+                                              float& x3, float& y3, float2 w0, float2 w1, float2 w2, float2 w3) {
+    float tmp;
+#define RMX_CM(X, Y, WR, WI)                                                                              \
+    "v_mul_f32 %8, %" #X ", %" #WI "\n\tv_mul_f32 %" #X ", %" #X ", %" #WR "\n\tv_fma_f32 %" #X ", -%" #Y \
+    ", %" #WI ", %" #X "\n\tv_fma_f32 %" #Y ", %" #Y ", %" #WR ", %8\n\t"
+    asm volatile(RMX_CM(0, 1, 9, 10) RMX_CM(2, 3, 11, 12) RMX_CM(4, 5, 13, 14) RMX_CM(6, 7, 15, 16)
+                 : "+v"(x0), "+v"(y0), "+v"(x1), "+v"(y1), "+v"(x2), "+v"(y2), "+v"(x3), "+v"(y3), "=&v"(tmp)
+                 : "s"(w0.x), "s"(w0.y), "s"(w1.x), "s"(w1.y), "s"(w2.x), "s"(w2.y), "s"(w3.x), "s"(w3.y));
+#undef RMX_CM
+}
+
 // W32^q, q = 0..15 (exp(-2*pi*i*q/32)): the per-slot part of the odd sub-transform's W_L^n.
 __device__ __forceinline__ float2 w32(int q) {
     constexpr float c[16] = {1.0f, 0.98078528040323044913f, 0.92387953251128675613f,
@@ -373,13 +387,19 @@ __device__ __forceinline__ float dpp_xor1(float x) {
 }
 
 // ---- wave64 reductions on the VALU (DPP row ops + 4 readlanes; no LDS traffic) -------------------
+// Each step is one v_max_f32_dpp / v_min_i32_dpp (x = op(x of the partner lane, x)); hipcc expands the
+// update_dpp builtin into v_mov + s_nop + v_mov_dpp + op instead, which doubles the length of this
+// dependent chain.  The 2 wait states between a VALU write and a DPP read of the same VGPR are ours
+// inside asm: s_nop 1 in front of every step.
 template <int CTRL>
 __device__ __forceinline__ int dpp_i(int x) { return __builtin_amdgcn_update_dpp(x, x, CTRL, 0xF, 0xF, false); }
+#define RMX_DPP_CHAIN(op)                                                                   \
+    "s_nop 1\n\t" op " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"      \
+    "s_nop 1\n\t" op " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"      \
+    "s_nop 1\n\t" op " %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"          \
+    "s_nop 1\n\t" op " %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf"
 __device__ __forceinline__ float wave_max_f32(float x) {
-    x = fmaxf(x, __builtin_bit_cast(float, dpp_i<0xB1>(__builtin_bit_cast(int, x))));   // quad_perm [1,0,3,2]
-    x = fmaxf(x, __builtin_bit_cast(float, dpp_i<0x4E>(__builtin_bit_cast(int, x))));   // quad_perm [2,3,0,1]
-    x = fmaxf(x, __builtin_bit_cast(float, dpp_i<0x141>(__builtin_bit_cast(int, x))));  // row_half_mirror
-    x = fmaxf(x, __builtin_bit_cast(float, dpp_i<0x140>(__builtin_bit_cast(int, x))));  // row_mirror
+    asm volatile(RMX_DPP_CHAIN("v_max_f32_dpp") : "+v"(x));       // every lane: max of its row of 16
     const int xi = __builtin_bit_cast(int, x);
     const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 0));
     const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 16));
@@ -388,13 +408,29 @@ __device__ __forceinline__ float wave_max_f32(float x) {
     return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 __device__ __forceinline__ int wave_min_i32(int x) {
-    x = min(x, dpp_i<0xB1>(x));
-    x = min(x, dpp_i<0x4E>(x));
-    x = min(x, dpp_i<0x141>(x));
-    x = min(x, dpp_i<0x140>(x));
+    asm volatile(RMX_DPP_CHAIN("v_min_i32_dpp") : "+v"(x));
     const int r0 = __builtin_amdgcn_readlane(x, 0), r1 = __builtin_amdgcn_readlane(x, 16);
     const int r2 = __builtin_amdgcn_readlane(x, 32), r3 = __builtin_amdgcn_readlane(x, 48);
     return min(min(r0, r1), min(r2, r3));
+}
+
+// qa..qd = Q0..Q0+3 where m0..m3 == tmax (else unchanged): four compares into four SGPR pairs, then
+// four selects.  hipcc funnels every compare through VCC and pays a wait state between each compare
+// and its select; with distinct masks nothing waits.
+template <int Q0>
+__device__ __forceinline__ void argsel4(int& qa, int& qb, int& qc, int& qd, float m0, float m1, float m2, float m3,
+                                        float tmax) {
+    unsigned long long k0, k1, k2, k3;
+    asm("v_cmp_eq_f32_e64 %4, %8, %12\n\t"
+        "v_cmp_eq_f32_e64 %5, %9, %12\n\t"
+        "v_cmp_eq_f32_e64 %6, %10, %12\n\t"
+        "v_cmp_eq_f32_e64 %7, %11, %12\n\t"
+        "v_cndmask_b32_e64 %0, %0, %13, %4\n\t"
+        "v_cndmask_b32_e64 %1, %1, %14, %5\n\t"
+        "v_cndmask_b32_e64 %2, %2, %15, %6\n\t"
+        "v_cndmask_b32_e64 %3, %3, %16, %7"
+        : "+v"(qa), "+v"(qb), "+v"(qc), "+v"(qd), "=&s"(k0), "=&s"(k1), "=&s"(k2), "=&s"(k3)
+        : "v"(m0), "v"(m1), "v"(m2), "v"(m3), "v"(tmax), "n"(Q0), "n"(Q0 + 1), "n"(Q0 + 2), "n"(Q0 + 3));
 }
 
 }  // namespace rmx

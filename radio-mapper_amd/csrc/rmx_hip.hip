@@ -641,13 +641,23 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
     // odd lanes: v[q] *= W32^q, the per-slot part of the odd sub-transform's W_L^n (in place)
     auto mul_w32_odd = [&](float2 (&v)[16]) __attribute__((always_inline)) {
         if (p) {
+            {   // q = 1..3 one by one, then three groups of four in one asm statement each
 #pragma unroll
-            for (int q = 1; q < 16; ++q) {
-                const float2 w = w32(q);
-                float x = v[q].x, y = v[q].y;   // scalars by value: keeps the array out of scratch
-                cmul_inplace(x, y, w.x, w.y);
-                v[q].x = x;
-                v[q].y = y;
+                for (int q = 1; q < 4; ++q) {
+                    const float2 w = w32(q);
+                    float x = v[q].x, y = v[q].y;   // scalars by value: keeps the array out of scratch
+                    cmul_inplace(x, y, w.x, w.y);
+                    v[q].x = x;
+                    v[q].y = y;
+                }
+            }
+#pragma unroll
+            for (int q = 4; q < 16; q += 4) {
+                float x0 = v[q].x, y0 = v[q].y, x1 = v[q + 1].x, y1 = v[q + 1].y;
+                float x2 = v[q + 2].x, y2 = v[q + 2].y, x3 = v[q + 3].x, y3 = v[q + 3].y;
+                cmul4_inplace(x0, y0, x1, y1, x2, y2, x3, y3, w32(q), w32(q + 1), w32(q + 2), w32(q + 3));
+                v[q].x = x0; v[q].y = y0; v[q + 1].x = x1; v[q + 1].y = y1;
+                v[q + 2].x = x2; v[q + 2].y = y2; v[q + 3].x = x3; v[q + 3].y = y3;
             }
         }
     };
@@ -845,9 +855,13 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
         float tmax = mag[0];
 #pragma unroll
         for (int q = 1; q < 16; ++q) tmax = fmaxf(tmax, mag[q]);
-        int qsel = 16;
-#pragma unroll
-        for (int q = 15; q >= 0; --q) qsel = (mag[q] == tmax) ? q : qsel;   // lowest slot holding the max
+        // lowest slot holding the max: four independent select chains
+        int qa = 16, qb = 16, qc = 16, qd = 16;
+        argsel4<12>(qa, qb, qc, qd, mag[12], mag[13], mag[14], mag[15], tmax);   // descending: lower slots win
+        argsel4<8>(qa, qb, qc, qd, mag[8], mag[9], mag[10], mag[11], tmax);
+        argsel4<4>(qa, qb, qc, qd, mag[4], mag[5], mag[6], mag[7], tmax);
+        argsel4<0>(qa, qb, qc, qd, mag[0], mag[1], mag[2], mag[3], tmax);
+        const int qsel = min(min(qa, qb), min(qc, qd));
         const int kq = kbase + qsel * 256;
         const float wmax = wave_max_f32(tmax);
         const int kw = wave_min_i32(tmax == wmax ? kq : 0x7fffffff);
