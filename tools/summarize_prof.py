@@ -30,23 +30,36 @@ def main():
         keep = [rows[0]] + [r for r in rows[1:] if any(k in r[0] for k in ours)]
         with open(os.path.join(out, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
             csv.writer(f).writerows(keep)
-    # full-size launches only (bench.py's parity leg launches the same kernel on 32 windows)
+    # full-size launches only: bench.py also launches the same kernel on 32 windows (parity leg) and on
+    # 512-window pieces (host-pointer leg, same persistent grid), so launches are kept by grid size AND
+    # by duration (at least half the median of the longer half)
+    def full_size(rows, gkey):
+        if not rows:
+            return []
+        gmax = max(int(r[gkey]) for r in rows)
+        rows = [r for r in rows if int(r[gkey]) == gmax]
+        d = sorted(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows)
+        ref = d[(len(d) * 3) // 4]
+        return [r for r in rows if int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) >= 0.5 * ref]
+
     tr = glob.glob(os.path.join(src, "stats", "*kernel_trace.csv"))
     if tr:
-        rows = [r for r in csv.DictReader(open(tr[0])) if any(k in r["Kernel_Name"] for k in ours)]
+        rows = full_size([r for r in csv.DictReader(open(tr[0])) if any(k in r["Kernel_Name"] for k in ours)], "Grid_Size_X")
         if rows:
-            gmax = max(int(r["Grid_Size_X"]) for r in rows)
-            d = sorted((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in rows if int(r["Grid_Size_X"]) == gmax)
+            d = sorted(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows)
             with open(os.path.join(out, f"{tag}_kernel_stats.csv"), "a", newline="") as f:
-                csv.writer(f).writerow([f"# full-size launches (grid {gmax}): n={len(d)} avg_ns={sum(d) / len(d):.0f} "
+                csv.writer(f).writerow([f"# full-size launches only: n={len(d)} avg_ns={sum(d) / len(d):.0f} "
                                         f"median_ns={d[len(d) // 2]} min_ns={d[0]} max_ns={d[-1]}"])
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for p in glob.glob(os.path.join(src, "pmc_*", "*counter_collection.csv")):
         rows = [r for r in csv.DictReader(open(p)) if any(k in r["Kernel_Name"] for k in ours)]
-        gmax = max([int(r["Grid_Size"]) for r in rows], default=0)
+        by_disp = collections.defaultdict(list)
         for r in rows:
-            name = r["Kernel_Name"].split("(")[0].split("<")[0]
-            if int(r["Grid_Size"]) == gmax:
+            by_disp[r["Dispatch_Id"]].append(r)
+        keep = {r["Dispatch_Id"] for r in full_size([v[0] for v in by_disp.values()], "Grid_Size")}
+        for r in rows:
+            if r["Dispatch_Id"] in keep:
+                name = r["Kernel_Name"].split("(")[0].split("<")[0]
                 agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
     pmc = {k: {c: sum(v) / len(v) for c, v in d.items()} | {"launches_sampled": len(next(iter(d.values())))}
            for k, d in agg.items()}
