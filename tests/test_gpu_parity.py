@@ -331,3 +331,16 @@ def test_error_codes_on_device(xc):
     with pytest.raises(xc.RmxError) as e:
         xc.XcorrEngine(3, 4096, 4, device=99)
     assert e.value.code == -1
+
+
+@pytest.mark.parametrize("logn", [21, 22])
+def test_longest_windows(xc, logn):
+    """The longest window lengths the ABI accepts (2 Mi and 4 Mi samples: L = 2^22, 2^23 -- row passes of
+    4096 / 8192 points) against the literal oracle, one pair."""
+    N = 1 << logn
+    iq, delays = rm.synth.make_windows(1, 2, N, 2.4e6, seed=900 + logn)
+    ri, rf, rp = orc.xcorr_batch_literal(iq)
+    with xc.XcorrEngine(2, N, 1) as eng:
+        li, lf, pk = eng.correlate(iq)
+    _assert_parity(li, lf, pk, ri, rf, rp)
+    assert abs((li + lf)[0, 0] - (delays[0, 1] - delays[0, 0])) < 0.5
