@@ -1544,7 +1544,12 @@ int rmx_create(rmx_ctx** out, int device_id, int n_buoys, int n_samples, int max
             if (chunk > cap) chunk = (int)(cap > 8 ? (cap & ~7L) : 8);
         }
         c->chunk_windows = chunk;
-        c->spec_bytes = (size_t)chunk * n_buoys * (8 * kThreads) * sizeof(float4);
+        // the fused kernel keeps its spectra per persistent workgroup (n_cus * B * 64 KiB); the
+        // per-window scratch of the unfused path (custom pair lists) is allocated on first use
+        {
+            const int wg = chunk < c->n_cus ? chunk : c->n_cus;
+            c->spec_bytes = (size_t)wg * n_buoys * (8 * kThreads) * sizeof(float4);
+        }
         RMX_HIP(c, hipMalloc((void**)&c->d_spec, c->spec_bytes));
         std::vector<float4> tw1;
         std::vector<float2> tw2;
@@ -1616,18 +1621,12 @@ int rmx_set_option(rmx_ctx* c, const char* key, long value) {
         long chunk = value < 8 ? 8 : value;
         chunk = (chunk + 7) & ~7L;
         if (chunk > c->max_windows) chunk = c->max_windows;
-        if (chunk != c->chunk_windows) {
-            RMX_HIP(c, hipSetDevice(c->device));
-            RMX_HIP(c, hipStreamSynchronize(c->stream));
-            const size_t nb = (size_t)chunk * c->n_buoys * (8 * kThreads) * sizeof(float4);
-            float4* nspec = nullptr;
-            RMX_HIP(c, hipMalloc((void**)&nspec, nb));
-            (void)hipFree(c->d_spec);
-            c->d_spec = nspec;
-            c->scratch_bytes += nb - c->spec_bytes;
-            c->spec_bytes = nb;
-            c->chunk_windows = (int)chunk;
+        {   // same 8 GiB cap on the unfused path's scratch as at creation
+            const long per_win = (long)c->n_buoys * (8 * kThreads) * (long)sizeof(float4);
+            const long cap = (8L << 30) / per_win;
+            if (chunk > cap) chunk = cap > 8 ? (cap & ~7L) : 8;
         }
+        c->chunk_windows = (int)chunk;   // (scratch follows on the next call: ensure_spec)
         return RMX_OK;
     }
     if (!strcmp(key, "pairs_per_block")) {
@@ -1652,6 +1651,20 @@ int rmx_set_option(rmx_ctx* c, const char* key, long value) {
         return RMX_OK;
     }
     return fail(c, RMX_E_INVAL, "unknown option '%s'", key);
+}
+
+// spectrum scratch of at least `windows` window slots (B * 64 KiB each)
+static int ensure_spec(rmx_ctx* c, long windows) {
+    const size_t nb = (size_t)windows * c->n_buoys * (8 * kThreads) * sizeof(float4);
+    if (nb <= c->spec_bytes) return RMX_OK;
+    RMX_HIP(c, hipStreamSynchronize(c->stream));
+    float4* nspec = nullptr;
+    RMX_HIP(c, hipMalloc((void**)&nspec, nb));
+    (void)hipFree(c->d_spec);
+    c->d_spec = nspec;
+    c->scratch_bytes += nb - c->spec_bytes;
+    c->spec_bytes = nb;
+    return RMX_OK;
 }
 
 int rmx_xcorr_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pairs, int n_pairs,
@@ -1736,6 +1749,12 @@ int rmx_xcorr_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pa
     const float fwd_scale = 1.0f;
     const float out_scale = std::ldexp(1.0f, 3 * kTw1ScaleLog2 - logl);
 
+    {   // scratch: per workgroup for the fused kernel, per window of a chunk otherwise
+        const bool fused_path = c->fused && c->plan_all_pairs;
+        const long chunk_w = n_windows < c->chunk_windows ? n_windows : c->chunk_windows;
+        rc = ensure_spec(c, fused_path ? (chunk_w < c->n_cus ? chunk_w : c->n_cus) : chunk_w);
+        if (rc != RMX_OK) return rc;
+    }
     const int n_parts = c->plan_n_parts;
     const int n_chunks = (n_windows + c->chunk_windows - 1) / c->chunk_windows;
     c->ev_used = 0;
