@@ -129,6 +129,23 @@ int rmx_solve_batch(rmx_ctx* ctx, const double* buoy_xyz, int n_buoys, const int
                     double sample_rate_hz, int n_windows, int max_iter, double* pos, double* cost,
                     int32_t* iters, unsigned flags);
 
+/* Spectral detection: the reference's per-capture detector
+ * (buoy_node.py:401-433, iq_stream_client.py:186-217) batched over windows.  Per window of n_samples
+ * (power of two, 16..16384; independent of the ctx's n_samples) complex samples:
+ *     P[k] = 20 log10(|FFT_N(iq)[k]| + 1e-12)                            (float32, unpadded, unwindowed)
+ *     peaks = scipy.signal.find_peaks(P, height=threshold_db, distance=distance)   (buoy_node.py:411-415)
+ *     floor = median(P); snr = P[peak] - floor; confidence = min(max(snr/20, 0), 1) (buoy_node.py:425-427)
+ *     a peak is reported unless |signed FFT bin| < dc_exclude_bins (the +-10 kHz of buoy_node.py:419,
+ *     i.e. 10e3 * n_samples / sample_rate) or confidence < min_confidence (0.3, buoy_node.py:430)
+ *   iq          complex64 [n_windows][n_samples] (or uint8 I,Q pairs with RMX_IN_U8); device with RMX_IN_DEVICE
+ *   count       int32 [n_windows]   peaks found (may exceed max_peaks; the arrays hold the first max_peaks,
+ *               in ascending bin order as find_peaks returns them)
+ *   bin / power_db / snr_db / confidence   [n_windows][max_peaks];  noise_floor_db float [n_windows]
+ *   (device pointers with RMX_OUT_DEVICE).  Frequency of a bin: fftfreq, f_centre + (bin < N/2 ? bin : bin - N) * fs / N. */
+int rmx_detect_batch(rmx_ctx* ctx, const void* iq, int n_windows, int n_samples, float threshold_db, int distance,
+                     double dc_exclude_bins, float min_confidence, int max_peaks, int32_t* count, int32_t* bin,
+                     float* power_db, float* snr_db, float* confidence, float* noise_floor_db, unsigned flags);
+
 /* Wait for all work queued on the ctx stream. */
 int rmx_synchronize(rmx_ctx* ctx);
 

@@ -26,6 +26,7 @@
 #include "../../include/rmx.h"
 #include "fft_r16.hpp"
 #include "generic_path.hpp"
+#include "detect_path.hpp"
 
 namespace rmx {
 
@@ -1182,6 +1183,9 @@ struct rmx_ctx {
     // host-pointer input of the fused path: copies pipelined against the kernels on a second stream
     hipStream_t copy_stream = nullptr;
     hipEvent_t copy_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // rmx_detect_batch: twiddle table of the last window length, dB spectra, staging
+    float2* dt_tw = nullptr;  int dt_logn = 0;  float* dt_pdb = nullptr;  size_t dt_pdb_bytes = 0;
+    void* dt_in = nullptr;  size_t dt_in_bytes = 0;  void* dt_out = nullptr;  size_t dt_out_bytes = 0;
     // rmx_solve_batch work buffers
     double* sv_buoys = nullptr;  int* sv_pairs = nullptr;  size_t sv_pairs_cap = 0;
     void* sv_in = nullptr;  size_t sv_in_bytes = 0;  void* sv_out = nullptr;  size_t sv_out_bytes = 0;
@@ -1584,6 +1588,8 @@ void rmx_destroy(rmx_ctx* c) {
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     for (hipEvent_t e : c->copy_ev)
         if (e) (void)hipEventDestroy(e);
+    for (void* p : {(void*)c->dt_tw, (void*)c->dt_pdb, c->dt_in, c->dt_out})
+        if (p) (void)hipFree(p);
     for (void* p : {(void*)c->sv_buoys, (void*)c->sv_pairs, c->sv_in, c->sv_out})
         if (p) (void)hipFree(p);
     if (c->caf_child) rmx_destroy(c->caf_child);
@@ -2044,6 +2050,88 @@ int rmx_solve_batch(rmx_ctx* c, const double* buoy_xyz, int n_buoys, const int32
         RMX_HIP(c, hipMemcpyAsync(pos, d_pos, (size_t)n_windows * 3 * 8, hipMemcpyDeviceToHost, c->stream));
         RMX_HIP(c, hipMemcpyAsync(cost, d_cost, (size_t)n_windows * 8, hipMemcpyDeviceToHost, c->stream));
         RMX_HIP(c, hipMemcpyAsync(iters, d_it, (size_t)n_windows * 4, hipMemcpyDeviceToHost, c->stream));
+        RMX_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    return RMX_OK;
+}
+
+int rmx_detect_batch(rmx_ctx* c, const void* iq, int n_windows, int n_samples, float threshold_db, int distance,
+                     double dc_exclude_bins, float min_confidence, int max_peaks, int32_t* count, int32_t* bin,
+                     float* power_db, float* snr_db, float* confidence, float* noise_floor_db, unsigned flags) {
+    if (!c) return RMX_E_INVAL;
+    if (!iq || !count || !bin || !power_db || !snr_db || !confidence || !noise_floor_db)
+        return fail(c, RMX_E_INVAL, "NULL buffer");
+    int logn = 0;
+    while ((1 << logn) < n_samples) ++logn;
+    if (n_samples < 16 || n_samples > 16384 || (1 << logn) != n_samples)
+        return fail(c, RMX_E_INVAL, "n_samples %d is not a power of two in 16..16384", n_samples);
+    if (n_windows < 0 || distance < 1 || max_peaks < 1)
+        return fail(c, RMX_E_INVAL, "n_windows %d, distance %d, max_peaks %d", n_windows, distance, max_peaks);
+    if (n_windows == 0) return RMX_OK;
+    RMX_HIP(c, hipSetDevice(c->device));
+    const int N = n_samples;
+    if (c->dt_logn != logn) {
+        std::vector<float2> t;
+        rmx::gen::make_row_table(t, N);
+        if (c->dt_tw) { RMX_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->dt_tw); c->dt_tw = nullptr; }
+        RMX_HIP(c, hipMalloc((void**)&c->dt_tw, t.size() * sizeof(float2)));
+        RMX_HIP(c, hipMemcpy(c->dt_tw, t.data(), t.size() * sizeof(float2), hipMemcpyHostToDevice));
+        c->dt_logn = logn;
+        RMX_HIP(c, hipFuncSetAttribute((const void*)rmx::det::d_fft_db<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8));
+        RMX_HIP(c, hipFuncSetAttribute((const void*)rmx::det::d_fft_db<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8));
+        RMX_HIP(c, hipFuncSetAttribute((const void*)rmx::det::d_peaks, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       16384 * 6 + 8192));
+    }
+    const bool in_dev = flags & RMX_IN_DEVICE, out_dev = flags & RMX_OUT_DEVICE, u8 = flags & RMX_IN_U8;
+    auto grow = [&](void** p, size_t* have, size_t need) -> int {
+        if (*have >= need) return RMX_OK;
+        RMX_HIP(c, hipStreamSynchronize(c->stream));
+        if (*p) (void)hipFree(*p);
+        *p = nullptr; *have = 0;
+        RMX_HIP(c, hipMalloc(p, need));
+        *have = need;
+        return RMX_OK;
+    };
+    int rc = grow((void**)&c->dt_pdb, &c->dt_pdb_bytes, (size_t)n_windows * N * sizeof(float));
+    if (rc != RMX_OK) return rc;
+    const void* d_iq = iq;
+    if (!in_dev) {
+        const size_t nb = (size_t)n_windows * N * (u8 ? 2 : 8);
+        rc = grow(&c->dt_in, &c->dt_in_bytes, nb);
+        if (rc != RMX_OK) return rc;
+        RMX_HIP(c, hipMemcpyAsync(c->dt_in, iq, nb, hipMemcpyHostToDevice, c->stream));
+        d_iq = c->dt_in;
+    }
+    int *d_count = count, *d_bin = bin;
+    float *d_pw = power_db, *d_snr = snr_db, *d_conf = confidence, *d_floor = noise_floor_db;
+    const size_t per = (size_t)n_windows * max_peaks;
+    if (!out_dev) {
+        rc = grow(&c->dt_out, &c->dt_out_bytes, per * 16 + (size_t)n_windows * 8);
+        if (rc != RMX_OK) return rc;
+        char* b = (char*)c->dt_out;
+        d_bin = (int*)b; d_pw = (float*)(b + per * 4); d_snr = (float*)(b + per * 8); d_conf = (float*)(b + per * 12);
+        d_count = (int*)(b + per * 16); d_floor = (float*)(b + per * 16 + (size_t)n_windows * 4);
+    }
+    const int fthr = N >= 4096 ? 1024 : (N >= 1024 ? 256 : 64);
+    if (u8)
+        hipLaunchKernelGGL(rmx::det::d_fft_db<true>, dim3(n_windows), dim3(fthr), (size_t)N * 8, c->stream, d_iq, c->dt_pdb,
+                           c->dt_tw, logn);
+    else
+        hipLaunchKernelGGL(rmx::det::d_fft_db<false>, dim3(n_windows), dim3(fthr), (size_t)N * 8, c->stream, d_iq, c->dt_pdb,
+                           c->dt_tw, logn);
+    RMX_HIP(c, hipGetLastError());
+    const int pthr = N >= 4096 ? 1024 : 256;
+    const size_t plds = (size_t)N * 4 + N + (size_t)N + 256 * 4 + 8 * 4 + (size_t)pthr * 4;
+    hipLaunchKernelGGL(rmx::det::d_peaks, dim3(n_windows), dim3(pthr), plds, c->stream, c->dt_pdb, logn, threshold_db, distance,
+                       dc_exclude_bins, min_confidence, max_peaks, d_count, d_bin, d_pw, d_snr, d_conf, d_floor);
+    RMX_HIP(c, hipGetLastError());
+    if (!out_dev) {
+        RMX_HIP(c, hipMemcpyAsync(bin, d_bin, per * 4, hipMemcpyDeviceToHost, c->stream));
+        RMX_HIP(c, hipMemcpyAsync(power_db, d_pw, per * 4, hipMemcpyDeviceToHost, c->stream));
+        RMX_HIP(c, hipMemcpyAsync(snr_db, d_snr, per * 4, hipMemcpyDeviceToHost, c->stream));
+        RMX_HIP(c, hipMemcpyAsync(confidence, d_conf, per * 4, hipMemcpyDeviceToHost, c->stream));
+        RMX_HIP(c, hipMemcpyAsync(count, d_count, (size_t)n_windows * 4, hipMemcpyDeviceToHost, c->stream));
+        RMX_HIP(c, hipMemcpyAsync(noise_floor_db, d_floor, (size_t)n_windows * 4, hipMemcpyDeviceToHost, c->stream));
         RMX_HIP(c, hipStreamSynchronize(c->stream));
     }
     return RMX_OK;

@@ -67,6 +67,8 @@ def load_library():
     lib.rmx_caf_batch.restype = ci
     lib.rmx_solve_batch.argtypes = [vp, vp, ci, vp, ci, vp, vp, vp, C.c_double, ci, ci, vp, vp, vp, cu]
     lib.rmx_solve_batch.restype = ci
+    lib.rmx_detect_batch.argtypes = [vp, vp, ci, ci, C.c_float, ci, C.c_double, C.c_float, ci, vp, vp, vp, vp, vp, vp, cu]
+    lib.rmx_detect_batch.restype = ci
     lib.rmx_synchronize.argtypes = [vp]
     lib.rmx_synchronize.restype = ci
     lib.rmx_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(ci), C.POINTER(C.c_float),
@@ -79,7 +81,7 @@ def load_library():
 
 
 EXPORTS = ["rmx_version", "rmx_device_count", "rmx_create", "rmx_destroy", "rmx_last_error",
-           "rmx_set_stream", "rmx_set_option", "rmx_xcorr_batch", "rmx_caf_batch", "rmx_solve_batch", "rmx_synchronize",
+           "rmx_set_stream", "rmx_set_option", "rmx_xcorr_batch", "rmx_caf_batch", "rmx_solve_batch", "rmx_detect_batch", "rmx_synchronize",
            "rmx_last_timing", "rmx_scratch_bytes"]
 
 
@@ -242,6 +244,38 @@ class XcorrEngine:
             lf.ctypes.data_as(C.c_void_p), wp, float(sample_rate_hz), W, int(max_iter),
             pos.ctypes.data_as(C.c_void_p), cost.ctypes.data_as(C.c_void_p), iters.ctypes.data_as(C.c_void_p), 0))
         return pos, cost, iters
+
+    def detect(self, iq: np.ndarray, threshold_db: float = -70.0, distance: int = 10, dc_exclude_bins: float = 0.0,
+               min_confidence: float = 0.3, max_peaks: int = 2048):
+        """Spectral detection (rmx_detect_batch), host arrays in and out.  iq: complex64 [W][N] (or uint8
+        [W][2N]).  Returns a list of W tuples (bins int32, power_db, snr_db, confidence float32 arrays,
+        noise_floor_db float)."""
+        iq = np.asarray(iq)
+        flags = 0
+        if iq.dtype == np.uint8:
+            flags |= RMX_IN_U8
+            W, N = iq.shape[0], iq.shape[1] // 2
+        else:
+            iq = np.ascontiguousarray(iq, dtype=np.complex64)
+            W, N = iq.shape
+        iq = np.ascontiguousarray(iq)
+        cnt = np.zeros(W, np.int32)
+        bins = np.zeros((W, max_peaks), np.int32)
+        pw = np.zeros((W, max_peaks), np.float32)
+        snr = np.zeros((W, max_peaks), np.float32)
+        conf = np.zeros((W, max_peaks), np.float32)
+        floor = np.zeros(W, np.float32)
+        if W == 0:
+            return []
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
+        self._check(self._lib.rmx_detect_batch(self._ctx, vp(iq), W, N, float(threshold_db), int(distance),
+                                               float(dc_exclude_bins), float(min_confidence), int(max_peaks), vp(cnt),
+                                               vp(bins), vp(pw), vp(snr), vp(conf), vp(floor), flags))
+        out = []
+        for w in range(W):
+            n = min(int(cnt[w]), max_peaks)
+            out.append((bins[w, :n].copy(), pw[w, :n].copy(), snr[w, :n].copy(), conf[w, :n].copy(), float(floor[w])))
+        return out
 
     def correlate_device(self, iq_ptr: int, n_windows: int, lag_int_ptr: int, lag_frac_ptr: int,
                          peak_ptr: int, pairs: Optional[np.ndarray] = None, u8: bool = False):
