@@ -306,17 +306,20 @@ __global__ __launch_bounds__(kGThreads) void g_rows(float2* __restrict__ data, c
 
 // ---- column passes of the four-step (no transposes through HBM) ----------------------------------
 // The L-point sequence is the row-major matrix [L1][L2], n = n1*L2 + n2.  A workgroup takes a tile of
-// kColT = 16 adjacent columns (128-byte row segments: full cache lines) with all L1 rows into LDS
+// T = 16 adjacent columns (128-byte row segments: full cache lines; 8 when L1 = 1024) with all L1 rows into LDS
 // ([L1][16], up to 128 KiB of the CU's 160 KiB), transforms the 16 columns there and writes the tile
 // back in place of a transpose + row pass + transpose.
-constexpr int kColLogT = 4, kColT = 1 << kColLogT;
+// columns per tile: 16 (128-byte row segments), or 8 when L1 = 1024 so that two 64 KiB tiles share a CU and
+// one workgroup's loads and stores overlap the other's butterflies (measured: cfg2 8.7 -> 8.1 ms)
+__host__ __device__ constexpr int col_log_t(int l1) { return l1 >= 10 ? 3 : 4; }
 // forward: zero-padded window -> out[k1'][n2] = W_L^(n2*k1) * sum_n1 x[n1][n2] W_L1^(n1*k1)
-//   (k1' = bit-reversed k1).  grid (L2/16, items); only the rows n1 < L1/2 are non-zero and read.
-template <bool U8>
+//   (k1' = bit-reversed k1).  grid (L2/T, items); only the rows n1 < L1/2 are non-zero and read.
+template <bool U8, int kColLogT>
 __global__ __launch_bounds__(1024) void g_cols_fwd(const void* __restrict__ iq, float2* __restrict__ out,
                                                    const float2* __restrict__ tw, int l1, int l2, long first_item,
                                                    int lo_bits, const float2* __restrict__ thi,
                                                    const float2* __restrict__ tlo) {
+    constexpr int kColT = 1 << kColLogT;
     extern __shared__ __attribute__((aligned(16))) char gsm[];
     float2* x = reinterpret_cast<float2*>(gsm);
     const int L1 = 1 << l1, L2 = 1 << l2, tid = threadIdx.x, nthr = blockDim.x;
@@ -358,10 +361,12 @@ __global__ __launch_bounds__(1024) void g_cols_fwd(const void* __restrict__ iq, 
     }
 }
 // inverse: in[k1'][n2] (after the inverse row pass and its twiddle) -> r[n1][n2] natural order, plus this
-// tile's partial argmax of |r|^2 in 'full' order.  grid (L2/16, slots); parts = L2/16.
+// tile's partial argmax of |r|^2 in 'full' order.  grid (L2/T, slots); parts = L2/T.
+template <int kColLogT>
 __global__ __launch_bounds__(1024) void g_cols_inv(const float2* __restrict__ in, float2* __restrict__ out,
                                                    const float2* __restrict__ tw, int l1, int l2,
                                                    float* __restrict__ pv, int* __restrict__ pk) {
+    constexpr int kColT = 1 << kColLogT;
     extern __shared__ __attribute__((aligned(16))) char gsm[];
     float2* x = reinterpret_cast<float2*>(gsm);
     const int L1 = 1 << l1, L2 = 1 << l2, tid = threadIdx.x, nthr = blockDim.x;

@@ -1333,12 +1333,12 @@ static size_t gen_rows_lds(int R) {                     // rows + per-row twiddl
     const int a = logR >> 1;
     return (size_t)(gen::kGThreads / tpr) * ((size_t)R + (1 << a) + (R >> a)) * 8;
 }
-static size_t gen_cols_lds(int l1) {                    // [L1][16] tile + 16 per-column twiddle tables
-    const int a = l1 >> 1;
-    return ((size_t)(1 << l1) * gen::kColT + (size_t)gen::kColT * ((1 << a) + ((1 << l1) >> a))) * 8;
+static size_t gen_cols_lds(int l1) {                    // [L1][T] tile + T per-column twiddle tables
+    const int a = l1 >> 1, T = 1 << gen::col_log_t(l1);
+    return ((size_t)(1 << l1) * T + (size_t)T * ((1 << a) + ((1 << l1) >> a))) * 8;
 }
 static int gen_cols_threads(int l1) {                   // one radix-4 work item per thread and pass, <= 1024
-    const long work = ((long)1 << l1) * gen::kColT / 4;
+    const long work = (((long)1 << l1) << gen::col_log_t(l1)) / 4;
     return work >= 1024 ? 1024 : (work < 64 ? 64 : (int)work);
 }
 
@@ -1375,9 +1375,12 @@ static int generic_init(rmx_ctx* c) {
         rc = upload(c, &c->g_tlo, tlo);
         if (rc) return rc;
         const int cols_lds = (int)gen_cols_lds(c->g_logL1), rows_lds = (int)gen_rows_lds(1 << c->g_logL2);
-        RMX_HIP(c, hipFuncSetAttribute((const void*)g_cols_fwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, cols_lds));
-        RMX_HIP(c, hipFuncSetAttribute((const void*)g_cols_fwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, cols_lds));
-        RMX_HIP(c, hipFuncSetAttribute((const void*)g_cols_inv, hipFuncAttributeMaxDynamicSharedMemorySize, cols_lds));
+        RMX_HIP(c, hipFuncSetAttribute((const void*)(g_cols_fwd<false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, cols_lds));
+        RMX_HIP(c, hipFuncSetAttribute((const void*)(g_cols_fwd<true, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, cols_lds));
+        RMX_HIP(c, hipFuncSetAttribute((const void*)(g_cols_inv<3>), hipFuncAttributeMaxDynamicSharedMemorySize, cols_lds));
+        RMX_HIP(c, hipFuncSetAttribute((const void*)(g_cols_fwd<false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, cols_lds));
+        RMX_HIP(c, hipFuncSetAttribute((const void*)(g_cols_fwd<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, cols_lds));
+        RMX_HIP(c, hipFuncSetAttribute((const void*)(g_cols_inv<4>), hipFuncAttributeMaxDynamicSharedMemorySize, cols_lds));
         RMX_HIP(c, hipFuncSetAttribute((const void*)(g_rows<true, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, rows_lds));
         RMX_HIP(c, hipFuncSetAttribute((const void*)(g_rows<false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, rows_lds));
     }
@@ -1410,7 +1413,7 @@ static int generic_ensure(rmx_ctx* c, int n_pairs) {
             const long big = items > slots ? items : slots;
             RMX_HIP(c, hipMalloc((void**)&c->g_prod, slots * L * 8));
             RMX_HIP(c, hipMalloc((void**)&c->g_tmp, big * L * 8));
-            const long parts = (1L << c->g_logL2) / kColT;       // one partial argmax per column tile
+            const long parts = (1L << c->g_logL2) >> col_log_t(c->g_logL1);   // one partial argmax per column tile
             RMX_HIP(c, hipMalloc((void**)&c->g_pv, slots * parts * sizeof(float)));
             RMX_HIP(c, hipMalloc((void**)&c->g_pk, slots * parts * sizeof(int)));
             c->g_slots_alloc = slots;
@@ -1462,21 +1465,26 @@ static int generic_batch(rmx_ctx* c, const void* d_iq, int n_windows, int n_pair
         const int cthr = gen_cols_threads(l1);
         const size_t clds = gen_cols_lds(l1), rlds = gen_rows_lds(L2);
         // forward: column pass (zero-padded window -> [k1'][n2] * W_L^(n2 k1)), row pass (-> [k1'][k2'])
-        if (u8)
-            hipLaunchKernelGGL(g_cols_fwd<true>, dim3(L2 / kColT, items), dim3(cthr), clds, st, d_iq, c->g_spec, c->g_tw1, l1, l2,
-                               first_item, c->g_lo_bits, c->g_thi, c->g_tlo);
-        else
-            hipLaunchKernelGGL(g_cols_fwd<false>, dim3(L2 / kColT, items), dim3(cthr), clds, st, d_iq, c->g_spec, c->g_tw1, l1, l2,
-                               first_item, c->g_lo_bits, c->g_thi, c->g_tlo);
+        const int lt = col_log_t(l1), ntiles = L2 >> lt;
+#define RMX_COLS_FWD(U8V, LT)                                                                                          \
+    hipLaunchKernelGGL((g_cols_fwd<U8V, LT>), dim3(ntiles, items), dim3(cthr), clds, st, d_iq, c->g_spec, c->g_tw1, l1, l2, \
+                       first_item, c->g_lo_bits, c->g_thi, c->g_tlo)
+        if (u8) { if (lt == 3) RMX_COLS_FWD(true, 3); else RMX_COLS_FWD(true, 4); }
+        else    { if (lt == 3) RMX_COLS_FWD(false, 3); else RMX_COLS_FWD(false, 4); }
+#undef RMX_COLS_FWD
         hipLaunchKernelGGL((g_rows<true, false, false>), rows_grid((long)items * L1, L2), dim3(kGThreads), rlds, st, c->g_spec,
                            c->g_tw2, l2, L1, l1, L, c->g_lo_bits, c->g_thi, c->g_tlo, fwd_scale, (long)items * L1);
         // pairs: row pass ([product on load] rows(L2)^-1 * conj W_L^(n2 k1)), column pass (-> r natural + partial argmax)
         hipLaunchKernelGGL((g_rows<false, true, true>), rows_grid((long)slots * L1, L2), dim3(kGThreads), rlds, st,
                            c->g_prod, c->g_tw2, l2, L1, l1, L, c->g_lo_bits, c->g_thi, c->g_tlo, 1.0f, (long)slots * L1,
                            c->g_spec, c->g_pairs, n_pairs, B);
-        hipLaunchKernelGGL(g_cols_inv, dim3(L2 / kColT, slots), dim3(cthr), clds, st, c->g_prod, c->g_tmp, c->g_tw1, l1, l2,
-                           c->g_pv, c->g_pk);
-        hipLaunchKernelGGL(g_final, dim3((slots + 63) / 64), dim3(64), 0, st, c->g_tmp, N, c->g_pv, c->g_pk, L2 / kColT,
+        if (lt == 3)
+            hipLaunchKernelGGL((g_cols_inv<3>), dim3(ntiles, slots), dim3(cthr), clds, st, c->g_prod, c->g_tmp, c->g_tw1, l1, l2,
+                               c->g_pv, c->g_pk);
+        else
+            hipLaunchKernelGGL((g_cols_inv<4>), dim3(ntiles, slots), dim3(cthr), clds, st, c->g_prod, c->g_tmp, c->g_tw1, l1, l2,
+                               c->g_pv, c->g_pk);
+        hipLaunchKernelGGL(g_final, dim3((slots + 63) / 64), dim3(64), 0, st, c->g_tmp, N, c->g_pv, c->g_pk, ntiles,
                            slots, (long)w0 * n_pairs, out_scale, d_lag, d_frac, d_peak);
         RMX_HIP(c, hipGetLastError());
     }
