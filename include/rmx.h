@@ -76,9 +76,11 @@ const char* rmx_last_error(const rmx_ctx* ctx);
 /* Use an existing hipStream_t (e.g. torch's current stream) for all work of this ctx. */
 int rmx_set_stream(rmx_ctx* ctx, void* hip_stream);
 
-/* Tuning knobs (all optional): "chunk_windows" (windows per forward/pair launch pair),
- * "pairs_per_block", "timing" (1: bracket every launch with HIP events).  Returns RMX_E_INVAL for
- * an unknown key. */
+/* Tuning knobs (all optional): "chunk_windows" (windows per launch), "timing" (1: bracket every
+ * launch with HIP events, read back with rmx_last_timing), "fused" (default 1; 0 forces the separate
+ * forward + pair kernels that custom pair lists use), "resident" and "pairs_per_block" (variants of
+ * that unfused pair kernel), "dbg" (ablation masks; only honoured by the -DRMX_ABLATE build).
+ * Returns RMX_E_INVAL for an unknown key. */
 int rmx_set_option(rmx_ctx* ctx, const char* key, long value);
 
 /* The hot path.
