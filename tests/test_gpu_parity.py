@@ -344,3 +344,83 @@ def test_longest_windows(xc, logn):
         li, lf, pk = eng.correlate(iq)
     _assert_parity(li, lf, pk, ri, rf, rp)
     assert abs((li + lf)[0, 0] - (delays[0, 1] - delays[0, 0])) < 0.5
+
+
+def test_cfg4_full_size_properties(xc):
+    """BASELINE cfg4 per GPU: 16 buoys (120 pairs) x 10 frequency channels x 512 windows = 5120 windows
+    of 4096 samples, generated on the device.  No oracle at this size: ground truth (the generator's
+    delays), closure lag(i,k) = lag(i,j) + lag(j,k) and a 64-window oracle subset."""
+    import torch
+    import bench
+    B, N, W, fs = 16, 4096, 5120, 10e6
+    dev = torch.device("cuda", 0)
+    x, delays = bench.synth_on_device(torch, dev, W, B, N, fs, seed=1004)
+    P = B * (B - 1) // 2
+    lag = torch.zeros((W, P), dtype=torch.int32, device=dev)
+    frac = torch.zeros((W, P), dtype=torch.float32, device=dev)
+    peak = torch.zeros((W, P), dtype=torch.float32, device=dev)
+    with xc.XcorrEngine(B, N, W) as eng:
+        eng.set_stream(torch.cuda.current_stream().cuda_stream)
+        eng.correlate_device(x.data_ptr(), W, lag.data_ptr(), frac.data_ptr(), peak.data_ptr())
+        torch.cuda.synchronize()
+    li, lf = lag.cpu().numpy(), frac.cpu().numpy()
+    pairs = orc.pair_list(B)
+    est = li + lf.astype(np.float64)
+    true = delays[:, pairs[:, 1]] - delays[:, pairs[:, 0]]
+    good = np.abs(est - true) < 0.5
+    assert good.mean() > 0.999, good.mean()          # 10 dB SNR: the rare miss is a noise peak
+    idx = {(int(i), int(j)): q for q, (i, j) in enumerate(pairs)}
+    clo = est[:, idx[(0, 1)]] + est[:, idx[(1, 2)]] - est[:, idx[(0, 2)]]
+    ok3 = good[:, idx[(0, 1)]] & good[:, idx[(1, 2)]] & good[:, idx[(0, 2)]]
+    assert np.abs(clo[ok3]).max() < 0.35             # three independent sub-sample estimates
+    sub = x[:64].cpu().numpy().view(np.complex64).reshape(64, B, N)
+    ri, rf, rp = orc.xcorr_batch_fast(sub, workers=8)
+    assert np.array_equal(li[:64], ri)
+    ref = ri + rf
+    assert np.all(np.abs(est[:64] - ref) <= TOL * np.maximum(np.abs(ref), 1.0))
+
+
+def test_cfg5_shape_ground_truth(xc):
+    """BASELINE cfg5 in one window: 32 buoys (496 pairs), 262144-sample windows at 20 MS/s, a 5-bin
+    Doppler grid (the oracle would need ~10 minutes here): every pair's lag within a sample of the
+    generator's delay and, for pairs whose relative Doppler sits on the grid, that bin."""
+    B, N, fs, D = 32, 262144, 20e6, 5
+    step = 50.0 / fs
+    grid = (np.arange(D) - D // 2) * step
+    rng = np.random.default_rng(5)
+    offs = rng.integers(-1, 2, size=B) * step              # per-buoy Doppler in {-50, 0, +50} Hz
+    iq, delays = rm.synth.make_windows(1, B, N, fs, seed=1005, doppler_cps=offs)
+    with xc.XcorrEngine(B, N, 1) as eng:
+        dop, li, lf, pk = eng.caf(iq, grid)
+    pairs = orc.pair_list(B)
+    true = delays[:, pairs[:, 1]] - delays[:, pairs[:, 0]]
+    assert np.all(np.abs(li + lf - true) < 1.0)
+    rel = np.rint((offs[pairs[:, 1]] - offs[pairs[:, 0]]) / step).astype(int) + D // 2     # in 0..4
+    assert np.array_equal(dop[0], rel)
+
+
+def test_cfg2_full_size_properties(xc):
+    """BASELINE cfg2: 3 buoys, 64 windows of 2^20 samples at 2.4 MS/s (four-step path), generated on the
+    device: ground truth, closure, and the literal oracle on two of the windows."""
+    import torch
+    import bench
+    B, N, W, fs = 3, 1 << 20, 64, 2.4e6
+    dev = torch.device("cuda", 0)
+    x, delays = bench.synth_on_device(torch, dev, W, B, N, fs, seed=1002)
+    lag = torch.zeros((W, 3), dtype=torch.int32, device=dev)
+    frac = torch.zeros((W, 3), dtype=torch.float32, device=dev)
+    peak = torch.zeros((W, 3), dtype=torch.float32, device=dev)
+    with xc.XcorrEngine(B, N, W) as eng:
+        eng.set_stream(torch.cuda.current_stream().cuda_stream)
+        eng.correlate_device(x.data_ptr(), W, lag.data_ptr(), frac.data_ptr(), peak.data_ptr())
+        torch.cuda.synchronize()
+    li, lf, pk = lag.cpu().numpy(), frac.cpu().numpy(), peak.cpu().numpy()
+    est = li + lf.astype(np.float64)
+    pairs = orc.pair_list(B)
+    true = delays[:, pairs[:, 1]] - delays[:, pairs[:, 0]]
+    assert np.abs(est - true).max() < 0.25            # 2^20 samples at 10 dB: far below a sample
+    # (0,1) + (1,2) = (0,2) up to the bias of three parabolic interpolations of a band-limited peak
+    assert np.abs(est[:, 0] + est[:, 2] - est[:, 1]).max() < 0.5
+    sub = x[:2].cpu().numpy().view(np.complex64).reshape(2, B, N)
+    ri, rf, rp = orc.xcorr_batch_literal(sub)
+    _assert_parity(li[:2], lf[:2], pk[:2], ri, rf, rp)
