@@ -91,6 +91,8 @@ int rmx_set_option(rmx_ctx* ctx, const char* key, long value);
  *   lag_int   int32   [n_windows][n_pairs]
  *   lag_frac  float32 [n_windows][n_pairs]   sub-sample offset in [-0.5, 0.5]
  *   peak      float32 [n_windows][n_pairs]   |c| at the integer peak (scipy scaling)
+ * Range: everything is float32 with exact power-of-two scaling inside; at N = 4096 the squared
+ * magnitudes stay finite for fully coherent inputs up to |sample| ~ 4e6 (rtl_sdr data is +-127.5).
  */
 int rmx_xcorr_batch(rmx_ctx* ctx, const void* iq, int n_windows, const int32_t* pairs, int n_pairs,
                     int32_t* lag_int, float* lag_frac, float* peak, unsigned flags);
