@@ -206,8 +206,10 @@ __device__ __forceinline__ void dft16_tw(float2 (&v)[16], const C16& w) {
 // for tw[q0 + 4*m], packed two per float4 from a 16-byte aligned base, so the row is eight full
 // ds_read_b128 (256 B/clk; the compiler pairs a row that starts on the unused tw[0] into
 // ds_read2_b64, 128 B/clk) and only ~8 twiddle registers are live at a time.
-__device__ __forceinline__ void dft16_tw_row_l1(float2 (&v)[16], const float4* row) {   // layer 1 only
-    const float4 f0 = row[0], f1 = row[1];
+// (f0, f1 = row[0], row[1] may be fetched by the caller BEFORE it issues the exchange reads that fill v:
+// a wave's LDS reads return in issue order, so twiddles requested behind the sixteen exchange reads
+// would hold the first butterfly group back until all sixteen have arrived)
+__device__ __forceinline__ void dft16_tw_row_l1(float2 (&v)[16], const float4* row, float4 f0, float4 f1) {   // layer 1 only
     dft4_tw<true>(v[0], v[4], v[8], v[12], make_float2(1.0f, 0.0f), make_float2(f0.x, f0.y), make_float2(f0.z, f0.w),
                   make_float2(f1.x, f1.y));
     const float4 f2 = row[2], f3 = row[3];
@@ -219,6 +221,13 @@ __device__ __forceinline__ void dft16_tw_row_l1(float2 (&v)[16], const float4* r
     const float4 f6 = row[6], f7 = row[7];
     dft4_tw<false>(v[3], v[7], v[11], v[15], make_float2(f5.z, f5.w), make_float2(f6.x, f6.y), make_float2(f6.z, f6.w),
                    make_float2(f7.x, f7.y));
+}
+__device__ __forceinline__ void dft16_tw_row_l1(float2 (&v)[16], const float4* row) {
+    dft16_tw_row_l1(v, row, row[0], row[1]);
+}
+__device__ __forceinline__ void dft16_tw_row(float2 (&v)[16], const float4* row, float4 f0, float4 f1) {
+    dft16_tw_row_l1(v, row, f0, f1);
+    dft16_layer2(v);
 }
 __device__ __forceinline__ void dft16_tw_row(float2 (&v)[16], const float4* row) {
     dft16_tw_row_l1(v, row);

@@ -758,12 +758,13 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
         barrier_hook(false);
         if (!(dbg & 8)) xchg_b_read(img, x, t);
         dft16(x);
+        const float4 r0 = tw2row[0], r1 = tw2row[1];   // ahead of the exchange reads (see dft16_tw_row_l1)
         if (!(dbg & 4)) {
         xchg_bc_write_b(img, x, t);
         wave_lds_order();
         xchg_bc_read_c(img, x, t);
         }
-        dft16_tw_row(x, tw2row);   // W_256^(n0*k1) as pre-twiddle of the last pass
+        dft16_tw_row(x, tw2row, r0, r1);   // W_256^(n0*k1) as pre-twiddle of the last pass
 #pragma unroll
         for (int q = 0; q < 16; ++q) xc.set(q, x[q].x, x[q].y);   // (scaled by 2^-6 through the TW1 table)
         ++seq;
@@ -803,11 +804,12 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
                 if (!(dbg & 16)) prefetch(kac);
             });
         }
+        const float4 r0 = tw2row[0], r1 = tw2row[1];   // ahead of the exchange reads (see dft16_tw_row_l1)
         if (!(dbg & 4)) {
             wave_lds_order();
             xchg_bc_read_b(img, v, t);
         }
-        dft16_tw_row_l1(v, tw2row);              // W_256^(n0*k1), k1 -> n1   (role B), layer 1
+        dft16_tw_row_l1(v, tw2row, r0, r1);      // W_256^(n0*k1), k1 -> n1   (role B), layer 1
         {
             float2* xb = img + (u >> 4) * kBcHalf + (u & 15) * 2 + p;   // own half-wave regions
             dft16_layer2_emit(v, [&](auto kac, const float2& x0, const float2& x1, const float2& x2, const float2& x3)
