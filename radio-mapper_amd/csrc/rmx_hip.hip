@@ -899,23 +899,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
 
     // ---- anchor 0: X_0 goes straight into the anchor registers (never stored); every other X_e is
     // transformed once, stored once for the later anchors, and used at once from registers for (0,e)
-    // The window samples come cold from HBM (the spectra, by contrast, are re-read out of the
-    // Infinity Cache): a request issued in the first half of pair (0,e) and used at the start of the
-    // next forward transform has ~2.4 us to arrive, which is not enough.  A third register buffer xn
-    // (live in this phase only) doubles the distance: X_{e+2}'s samples are requested into xn while
-    // pair (0,e) runs, and move from xn to sb one pair later.
-    C16 xn;
-    auto copy_x_part = [&](C16& d, const C16& s, auto part) __attribute__((always_inline)) {
-        constexpr int G = decltype(part)::value;
-#pragma unroll
-        for (int q = 4 * G; q < 4 * G + 4; ++q) {
-            d.re[q] = s.re[q];
-            if constexpr (!U8) d.im[q] = s.im[q];
-        }
-    };
     load_x(sa, 0);
-    if (B > 1) load_x(sb, 1);          // sb and xn are free: these travel while X_0 is transformed
-    if (B > 2) load_x(xn, 2);
+    if (B > 1) load_x(sb, 1);          // sb is free: X_1's samples travel while X_0 is transformed
     cvt_x(sa);
     fwd(sa);
     // (the last buoy is peeled off the loop: its pair requests spectra instead of samples; with both
@@ -925,10 +910,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
         cvt_x(sb);
         fwd(sb);
         store_spec(sb, e);
-        pair(sa, sb, out_of(0, e), [&](auto part) __attribute__((always_inline)) {
-            copy_x_part(sb, xn, part);                       // X_{e+1}'s samples, requested a pair ago
-            if (e + 2 < B) load_x_part(xn, e + 2, part);
-        });
+        pair(sa, sb, out_of(0, e), [&](auto part) __attribute__((always_inline)) { load_x_part(sb, e + 1, part); });
     }
     if (B > 1) {
         cvt_x(sb);
