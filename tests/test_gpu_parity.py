@@ -424,3 +424,18 @@ def test_cfg2_full_size_properties(xc):
     sub = x[:2].cpu().numpy().view(np.complex64).reshape(2, B, N)
     ri, rf, rp = orc.xcorr_batch_literal(sub)
     _assert_parity(li[:2], lf[:2], pk[:2], ri, rf, rp)
+
+
+def test_repeated_calls_are_bit_identical(xc):
+    """The fused kernel has no atomics on its data path; its LDS protocol (alternating exchange images,
+    record ring, half-transform staggering, persistent workgroups) must give the same bits on every
+    run: 12 repeats over 1024 windows, any race would show up as a differing lag, fraction or peak."""
+    iq, _ = rm.synth.make_windows(1024, 8, 4096, 10e6, seed=4242)
+    with xc.XcorrEngine(8, 4096, 1024) as eng:
+        li0, lf0, pk0 = eng.correlate(iq)
+        for _ in range(11):
+            li, lf, pk = eng.correlate(iq)
+            assert np.array_equal(li, li0) and np.array_equal(lf, lf0) and np.array_equal(pk, pk0)
+    with xc.XcorrEngine(8, 4096, 1024) as eng2:      # and across engines
+        li, lf, pk = eng2.correlate(iq)
+        assert np.array_equal(li, li0) and np.array_equal(lf, lf0) and np.array_equal(pk, pk0)
