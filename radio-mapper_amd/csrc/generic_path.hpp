@@ -2,11 +2,12 @@
 //
 // N = 4096 (BASELINE cfg3/cfg4) has the register/LDS-resident radix-16 kernels of rmx_hip.hip.  All
 // other lengths run here: simpler kernels, same definition, same output contract.
-//   L = 2N <= 8192   one workgroup per transform, the whole zero-padded window in LDS:
+//   L = 2N <= 16384  one workgroup per transform, the whole zero-padded window in LDS (128 KiB at L = 16384,
+//                    i.e. the reference's 8192-sample captures):
 //                      g_fwd_small   (window, buoy)  : radix-2 DIF, spectrum left in bit-reversed order
 //                      g_pair_small  (window, pair)  : X_j conj(X_i) -> radix-2 DIT (takes bit-reversed
 //                                                      input, natural output) -> |.|, argmax, parabola
-//   L = 2N  > 8192   four-step transform through HBM in two passes per transform, no transposes: the
+//   L = 2N  > 16384  four-step transform through HBM in two passes per transform, no transposes: the
 //                    sequence is the row-major matrix [L1][L2] (L1 <= 1024 columns-length, L2 = L/L1
 //                    <= 8192), n = n1*L2 + n2:
 //                      forward : g_cols_fwd  tiles of 16 columns x all L1 rows in LDS (up to 128 KiB of
@@ -159,14 +160,14 @@ __device__ __forceinline__ float parabola(float a, float b, float c) {
 // ---- small path -------------------------------------------------------------------------------
 // spectrum layout: [item][L] complex, bit-reversed order, scaled by `scale`
 template <bool U8>
-__global__ __launch_bounds__(kGThreads) void g_fwd_small(const void* __restrict__ iq, float2* __restrict__ spec,
+__global__ __launch_bounds__(1024) void g_fwd_small(const void* __restrict__ iq, float2* __restrict__ spec,
                                                          const float2* __restrict__ tw, int N, int logL,
                                                          long first_item, float scale) {
     extern __shared__ __attribute__((aligned(16))) char gsm[];
     float2* x = reinterpret_cast<float2*>(gsm);
-    const int L = 1 << logL, tid = threadIdx.x;
+    const int L = 1 << logL, tid = threadIdx.x, nthr = blockDim.x;
     const long item = first_item + blockIdx.x;
-    for (int n = tid; n < L; n += kGThreads) {
+    for (int n = tid; n < L; n += nthr) {
         float2 v = make_float2(0.f, 0.f);
         if (n < N) {
             if constexpr (U8) {
@@ -179,16 +180,16 @@ __global__ __launch_bounds__(kGThreads) void g_fwd_small(const void* __restrict_
         x[n] = v;
     }
     __syncthreads();
-    lds_dif(x, logL, tw, tid, kGThreads);
+    lds_dif(x, logL, tw, tid, nthr);
     float2* out = spec + (long)blockIdx.x * L;
-    for (int n = tid; n < L; n += kGThreads) out[n] = make_float2(x[n].x * scale, x[n].y * scale);
+    for (int n = tid; n < L; n += nthr) out[n] = make_float2(x[n].x * scale, x[n].y * scale);
 }
 
 struct GPair {
     int i, j;
 };
 
-__global__ __launch_bounds__(kGThreads) void g_pair_small(const float2* __restrict__ spec,
+__global__ __launch_bounds__(1024) void g_pair_small(const float2* __restrict__ spec,
                                                           const float2* __restrict__ tw,
                                                           const GPair* __restrict__ pairs, int n_pairs,
                                                           int n_buoys, int N, int logL, long first_window,
@@ -196,25 +197,25 @@ __global__ __launch_bounds__(kGThreads) void g_pair_small(const float2* __restri
                                                           float* __restrict__ lag_frac, float* __restrict__ peak) {
     extern __shared__ __attribute__((aligned(16))) char gsm[];
     float2* x = reinterpret_cast<float2*>(gsm);
-    const int L = 1 << logL, tid = threadIdx.x;
+    const int L = 1 << logL, tid = threadIdx.x, nthr = blockDim.x;
     float* sv = reinterpret_cast<float*>(gsm + (size_t)L * 8);
-    int* sk = reinterpret_cast<int*>(sv + kGThreads);
+    int* sk = reinterpret_cast<int*>(sv + nthr);
     const int wl = blockIdx.x / n_pairs, q = blockIdx.x % n_pairs;
     const GPair pr = pairs[q];
     const float2* xi = spec + ((long)wl * n_buoys + pr.i) * L;
     const float2* xj = spec + ((long)wl * n_buoys + pr.j) * L;
-    for (int n = tid; n < L; n += kGThreads) x[n] = g_cmulc(xj[n], xi[n]);   // X_j conj(X_i)
+    for (int n = tid; n < L; n += nthr) x[n] = g_cmulc(xj[n], xi[n]);   // X_j conj(X_i)
     __syncthreads();
-    lds_dit_inv(x, logL, tw, tid, kGThreads);
+    lds_dit_inv(x, logL, tw, tid, nthr);
     float best = -1.0f;
     int bk = 0x7fffffff;
-    for (int m = tid; m < L; m += kGThreads) {
+    for (int m = tid; m < L; m += nthr) {
         const int k = full_index(m, N);
         if (k < 0) continue;
         const float v = x[m].x * x[m].x + x[m].y * x[m].y;
         if (v > best || (v == best && k < bk)) { best = v; bk = k; }
     }
-    block_argmax(best, bk, sv, sk, tid, kGThreads);
+    block_argmax(best, bk, sv, sk, tid, nthr);
     if (tid == 0) {
         const float b = sqrtf(best) * out_scale;
         float frac = 0.0f;

@@ -1309,6 +1309,9 @@ static int upload(rmx_ctx* c, float2** dst, const std::vector<float2>& v) {
     return RMX_OK;
 }
 
+// windows up to this zero-padded length run with the whole transform in LDS (128 KiB of the 160)
+static constexpr long kGenSmallMaxL = 16384;
+static int gen_small_threads(long L) { return L >= 8192 ? 1024 : 256; }
 // dynamic LDS of the four-step kernels
 static size_t gen_rows_lds(int R) {                     // rows + per-row twiddle tables (TW passes)
     const int tpr = (R >> 2) < gen::kGThreads ? ((R >> 2) > 0 ? (R >> 2) : 1) : gen::kGThreads;
@@ -1335,12 +1338,14 @@ static int generic_init(rmx_ctx* c) {
     const long L = 1L << c->g_logL;
     const int all_pairs = c->n_buoys * (c->n_buoys - 1) / 2;
     std::vector<float2> t;
-    if (L <= 8192) {
+    if (L <= kGenSmallMaxL) {
         make_row_table(t, (int)L);
         int rc = upload(c, &c->g_tw, t);
         if (rc) return rc;
-        RMX_HIP(c, hipFuncSetAttribute((const void*)g_pair_small, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)(L * 8 + kGThreads * 8)));
+        const int slds = (int)(L * 8 + gen_small_threads(L) * 8);
+        RMX_HIP(c, hipFuncSetAttribute((const void*)g_pair_small, hipFuncAttributeMaxDynamicSharedMemorySize, slds));
+        RMX_HIP(c, hipFuncSetAttribute((const void*)g_fwd_small<false>, hipFuncAttributeMaxDynamicSharedMemorySize, slds));
+        RMX_HIP(c, hipFuncSetAttribute((const void*)g_fwd_small<true>, hipFuncAttributeMaxDynamicSharedMemorySize, slds));
     } else {
         // columns of length L1 <= 1024 (a tile of 16 columns is L1*128 bytes of LDS), rows of L2 = L/L1 <= 8192
         c->g_logL1 = c->g_logL / 2 < 10 ? c->g_logL / 2 : 10;
@@ -1386,7 +1391,7 @@ static int generic_ensure(rmx_ctx* c, int n_pairs) {
         RMX_HIP(c, hipMalloc((void**)&c->g_spec, items * L * 8));
         c->scratch_bytes += items * L * 8;
     }
-    if (L > 8192) {
+    if (L > kGenSmallMaxL) {
         // (re)allocate the pair-dependent buffers when the pair count grows
         if (slots > c->g_slots_alloc) {
             if (c->g_prod) { (void)hipFree(c->g_prod); c->g_prod = nullptr; }
@@ -1428,14 +1433,15 @@ static int generic_batch(rmx_ctx* c, const void* d_iq, int n_windows, int n_pair
         const int wc = n_windows - w0 < c->g_chunk ? n_windows - w0 : c->g_chunk;
         const int items = wc * B, slots = wc * n_pairs;
         const long first_item = (long)w0 * B;
-        if (L <= 8192) {
+        if (L <= kGenSmallMaxL) {
+            const int sthr = gen_small_threads(L);
             if (u8)
-                hipLaunchKernelGGL(g_fwd_small<true>, dim3(items), dim3(kGThreads), (size_t)L * 8, st, d_iq, c->g_spec,
+                hipLaunchKernelGGL(g_fwd_small<true>, dim3(items), dim3(sthr), (size_t)L * 8, st, d_iq, c->g_spec,
                                    c->g_tw, N, logL, first_item, fwd_scale);
             else
-                hipLaunchKernelGGL(g_fwd_small<false>, dim3(items), dim3(kGThreads), (size_t)L * 8, st, d_iq, c->g_spec,
+                hipLaunchKernelGGL(g_fwd_small<false>, dim3(items), dim3(sthr), (size_t)L * 8, st, d_iq, c->g_spec,
                                    c->g_tw, N, logL, first_item, fwd_scale);
-            hipLaunchKernelGGL(g_pair_small, dim3(slots), dim3(kGThreads), (size_t)L * 8 + kGThreads * 8, st, c->g_spec,
+            hipLaunchKernelGGL(g_pair_small, dim3(slots), dim3(sthr), (size_t)L * 8 + (size_t)sthr * 8, st, c->g_spec,
                                c->g_tw, c->g_pairs, n_pairs, B, N, logL, (long)w0, out_scale, d_lag, d_frac, d_peak);
             RMX_HIP(c, hipGetLastError());
             continue;

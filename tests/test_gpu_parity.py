@@ -439,3 +439,16 @@ def test_repeated_calls_are_bit_identical(xc):
     with xc.XcorrEngine(8, 4096, 1024) as eng2:      # and across engines
         li, lf, pk = eng2.correlate(iq)
         assert np.array_equal(li, li0) and np.array_equal(lf, lf0) and np.array_equal(pk, pk0)
+
+
+@pytest.mark.parametrize("N", [16, 64, 512, 2048, 8192, 32768, 131072])
+def test_every_path_by_window_length(xc, N):
+    """One seeded case per kernel family boundary: LDS-resident transforms up to L = 16384 (N = 8192 is
+    the reference's iq_stream_client capture length), four-step above; against the oracle."""
+    W = 3 if N <= 8192 else 1
+    iq, delays = rm.synth.make_windows(W, 3, N, 2.4e6, seed=700 + N % 997)
+    ri, rf, rp = orc.xcorr_batch_literal(iq)
+    margin = np.array([[orc.peak_margin(iq[w, i], iq[w, j]) for (i, j) in orc.pair_list(3)] for w in range(W)])
+    with xc.XcorrEngine(3, N, W) as eng:
+        li, lf, pk = eng.correlate(iq)
+    _assert_parity(li, lf, pk, ri, rf, rp, margin)
