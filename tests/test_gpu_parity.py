@@ -452,3 +452,49 @@ def test_every_path_by_window_length(xc, N):
     with xc.XcorrEngine(3, N, W) as eng:
         li, lf, pk = eng.correlate(iq)
     _assert_parity(li, lf, pk, ri, rf, rp, margin)
+
+
+def test_mixed_call_patterns_on_one_engine(xc):
+    """Fused and unfused calls interleaved on one ctx (the unfused path allocates its per-window scratch on
+    first use and the fused path keeps working after it), shrinking and growing window counts, and the
+    IQ -> lags -> positions chain entirely through device pointers on one stream."""
+    import ctypes as C
+    import torch
+    B, N = 5, 4096
+    iq, delays = rm.synth.make_windows(40, B, N, 10e6, seed=808)
+    sel = np.array([[0, 4], [2, 3], [1, 4]], np.int32)
+    allp = orc.pair_list(B)
+    cols = [int(np.where((allp == p).all(axis=1))[0][0]) for p in sel]
+    with xc.XcorrEngine(B, N, 40) as eng:
+        s0 = eng.scratch_bytes()
+        a = eng.correlate(iq)                       # fused
+        b = eng.correlate(iq, sel)                  # unfused: custom pairs
+        assert eng.scratch_bytes() >= s0            # (40 windows < 256 CUs: both paths need 40 window slots)
+        c = eng.correlate(iq[:7])                   # fused again, fewer windows
+        d = eng.correlate(iq)                       # and all of them
+        assert np.array_equal(a[0][:, cols], b[0]) and np.allclose(a[1][:, cols], b[1], atol=TOL)
+        assert all(np.array_equal(x[:7], y) for x, y in zip(a, c))
+        assert all(np.array_equal(x, y) for x, y in zip(a, d))
+        # device chain
+        dev = torch.device("cuda", 0)
+        eng.set_stream(torch.cuda.current_stream().cuda_stream)
+        x = torch.from_numpy(iq.view(np.float32).reshape(40, B, N, 2)).to(dev)
+        P = len(allp)
+        lag = torch.zeros((40, P), dtype=torch.int32, device=dev)
+        frac = torch.zeros((40, P), dtype=torch.float32, device=dev)
+        peak = torch.zeros((40, P), dtype=torch.float32, device=dev)
+        pos = torch.zeros((40, 3), dtype=torch.float64, device=dev)
+        cost = torch.zeros(40, dtype=torch.float64, device=dev)
+        its = torch.zeros(40, dtype=torch.int32, device=dev)
+        eng.correlate_device(x.data_ptr(), 40, lag.data_ptr(), frac.data_ptr(), peak.data_ptr())
+        rng = np.random.default_rng(1)
+        buoys = np.ascontiguousarray(rng.normal(0, 2e4, (B, 3)) + np.array([3.9e6, -7e3, 4.9e6]))
+        lib = xc.load_library()
+        vp = lambda tns: C.c_void_p(tns.data_ptr())   # noqa: E731
+        rc = lib.rmx_solve_batch(eng._ctx, buoys.ctypes.data_as(C.c_void_p), B, None, P, vp(lag), vp(frac), None,
+                                 10e6, 40, 60, vp(pos), vp(cost), vp(its), 3)
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(lag.cpu().numpy(), a[0]) and np.array_equal(frac.cpu().numpy(), a[1])
+        hp, hc, hi = eng.solve(buoys, a[0], a[1], 10e6)
+        assert np.array_equal(pos.cpu().numpy(), hp) and np.array_equal(its.cpu().numpy(), hi)
