@@ -263,6 +263,10 @@ __global__ __launch_bounds__(kGThreads) void g_rows(float2* __restrict__ data, c
     const long ridx = (long)blockIdx.x * rpw + g;
     const bool live = ridx < total_rows;
     float2* x = reinterpret_cast<float2*>(gsm) + (long)g * R;
+    // the row's twiddle table goes to LDS once (butterflies would otherwise fetch two entries per
+    // radix-4 group through the vector memory path, a dependent cache-latency access in the inner loop)
+    float2* twl = reinterpret_cast<float2*>(gsm) + (long)rpw * R + (TW ? (long)rpw * ((1 << (logR >> 1)) + (R >> (logR >> 1))) : 0);
+    for (int k = threadIdx.x; k < (R >> 1); k += kGThreads) twl[k] = tw[k];
     float2* row = data + ridx * R;
     const int rib = (int)(ridx & (n_rows - 1));   // row index inside its batch element (n_rows = 2^row_bits)
     if (live) {
@@ -278,7 +282,7 @@ __global__ __launch_bounds__(kGThreads) void g_rows(float2* __restrict__ data, c
         }
     }
     __syncthreads();
-    if (FWD) lds_dif(x, logR, tw, tid, tpr); else lds_dit_inv(x, logR, tw, tid, tpr);
+    if (FWD) lds_dif(x, logR, twl, tid, tpr); else lds_dit_inv(x, logR, twl, tid, tpr);
     if constexpr (TW) {
         // W_L^(c*e) for this row's fixed multiplier c and every exponent e < R, as the product of two
         // per-row LDS tables T1[e & (2^a - 1)] * T2[e >> a] (2^a + R/2^a big-table lookups per row
@@ -327,6 +331,8 @@ __global__ __launch_bounds__(1024) void g_cols_fwd(const void* __restrict__ iq, 
     const long L = (long)L1 << l2, N = L >> 1;
     const int c0 = blockIdx.x * kColT;
     const long item = first_item + blockIdx.y;
+    float2* twl = x + ((long)L1 << kColLogT) + (long)kColT * ((1 << (l1 >> 1)) + (L1 >> (l1 >> 1)));   // behind x and the tables
+    for (int k = tid; k < (L1 >> 1); k += nthr) twl[k] = tw[k];
     for (int idx = tid; idx < (L1 << kColLogT); idx += nthr) {
         const int c = idx & (kColT - 1), n1 = idx >> kColLogT;
         float2 v = make_float2(0.f, 0.f);
@@ -342,7 +348,7 @@ __global__ __launch_bounds__(1024) void g_cols_fwd(const void* __restrict__ iq, 
         x[idx] = v;
     }
     __syncthreads();
-    lds_dif<kColLogT>(x, l1, tw, tid, nthr);
+    lds_dif<kColLogT>(x, l1, twl, tid, nthr);
     // per-column twiddle tables: W_L^(n2*e) = T1[e & (2^a-1)] * T2[e >> a]   (n2*e < L: no reduction)
     const int a = l1 >> 1, na = 1 << a, nb = L1 >> a;
     float2* tab = x + ((long)L1 << kColLogT);               // [16][na + nb]
@@ -374,11 +380,13 @@ __global__ __launch_bounds__(1024) void g_cols_inv(const float2* __restrict__ in
     const long L = (long)L1 << l2;
     const int N = (int)(L >> 1);
     const int c0 = blockIdx.x * kColT;
+    float2* twl = x + ((long)L1 << kColLogT) + (long)kColT * ((1 << (l1 >> 1)) + (L1 >> (l1 >> 1)));
+    for (int k = tid; k < (L1 >> 1); k += nthr) twl[k] = tw[k];
     const float2* src = in + (long)blockIdx.y * L;
     for (int idx = tid; idx < (L1 << kColLogT); idx += nthr)
         x[idx] = src[(long)(idx >> kColLogT) * L2 + c0 + (idx & (kColT - 1))];
     __syncthreads();
-    lds_dit_inv<kColLogT>(x, l1, tw, tid, nthr);
+    lds_dit_inv<kColLogT>(x, l1, twl, tid, nthr);
     float2* o = out + (long)blockIdx.y * L;
     float best = -1.0f;
     int bk = 0x7fffffff;

@@ -1318,11 +1318,11 @@ static size_t gen_rows_lds(int R) {                     // rows + per-row twiddl
     int logR = 0;
     while ((1 << logR) < R) ++logR;
     const int a = logR >> 1;
-    return (size_t)(gen::kGThreads / tpr) * ((size_t)R + (1 << a) + (R >> a)) * 8;
+    return ((size_t)(gen::kGThreads / tpr) * ((size_t)R + (1 << a) + (R >> a)) + (size_t)(R >> 1)) * 8;   // + W_R table
 }
 static size_t gen_cols_lds(int l1) {                    // [L1][T] tile + T per-column twiddle tables
     const int a = l1 >> 1, T = 1 << gen::col_log_t(l1);
-    return ((size_t)(1 << l1) * T + (size_t)T * ((1 << a) + ((1 << l1) >> a))) * 8;
+    return ((size_t)(1 << l1) * T + (size_t)T * ((1 << a) + ((1 << l1) >> a)) + (size_t)((1 << l1) >> 1)) * 8;   // + W_L1 table
 }
 static int gen_cols_threads(int l1) {                   // one radix-4 work item per thread and pass, <= 1024
     const long work = (((long)1 << l1) << gen::col_log_t(l1)) / 4;
