@@ -129,10 +129,8 @@ __global__ __launch_bounds__(kThreads, 4) void k_fwd(const void* __restrict__ iq
 // ------------------------------------------------------------------------------------------------
 // Pair kernel.  grid = n_windows_in_chunk * n_parts; each workgroup walks items[part_begin..end).
 //   out arrays are indexed [(first_window + wl) * n_pairs + item.out].
-// RESIDENT = true : one workgroup per CU (<= 256 VGPRs): TW1 and the anchor spectrum X_i stay in
-//                   registers across pairs; only X_j streams, requested one whole pair ahead.
-// RESIDENT = false: two workgroups per CU (<= 128 VGPRs): TW1 and X_i are re-read every pair.
-template <bool RESIDENT>
+// Streaming variant (k_pair_str, option "resident" = 0): two workgroups per CU (<= 128 VGPRs); TW1,
+// X_i and X_j are re-read every pair.  The resident variant is k_pair_res below.
 __device__ __forceinline__ void pair_body(const float4* __restrict__ spec, const float4* __restrict__ tw1_g,
                                           const float2* __restrict__ tw2_g, const PairItem* __restrict__ items,
                                           const int* __restrict__ part_begin, int n_parts, int n_buoys,
@@ -167,8 +165,6 @@ __device__ __forceinline__ void pair_body(const float4* __restrict__ spec, const
     }
 
     load_tw2_to_lds(tw2_lds, tw2_g, t);
-    float2 tw1r[16];
-    if constexpr (RESIDENT) load_tw1(tw1r, tw1_g, t);
     __syncthreads();
 
     const float sgn = p ? -1.0f : 1.0f;
@@ -177,7 +173,6 @@ __device__ __forceinline__ void pair_body(const float4* __restrict__ spec, const
     const long wbase = (long)wl * n_buoys;
     float4 sa[8], sb[8];   // X_i (anchor) and X_j of the pair about to be processed
     PairItem pi = items[it_begin < it_end ? it_begin : 0];
-    int cur_i = pi.i;
     if (it_begin < it_end) {
         const float4* xi = spec + (wbase + pi.i) * (8 * kThreads);
         const float4* xj = spec + (wbase + pi.j) * (8 * kThreads);
@@ -199,21 +194,6 @@ __device__ __forceinline__ void pair_body(const float4* __restrict__ spec, const
             v[2 * j] = make_float2(b.y * a.x - b.x * a.y, b.x * a.x + b.y * a.y);
             v[2 * j + 1] = make_float2(b.w * a.z - b.z * a.w, b.z * a.z + b.w * a.w);
         }
-        if constexpr (RESIDENT) {
-            // request the next pair's spectra now: a whole pair of compute hides the latency
-            if (it + 1 < it_end) {
-                pi = items[it + 1];
-                const float4* xj = spec + (wbase + pi.j) * (8 * kThreads);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) sb[j] = xj[j * kThreads + t];
-                if (pi.i != cur_i) {
-                    cur_i = pi.i;
-                    const float4* xi = spec + (wbase + pi.i) * (8 * kThreads);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) sa[j] = xi[j * kThreads + t];
-                }
-            }
-        }
         dft16(v);                     // k2 -> n0   (role C)
         mul_tw2(v, tw2_lds, u & 15);  // W_256^(k1*n0)
         xchg_bc_write_c(xl, v, t);
@@ -221,7 +201,7 @@ __device__ __forceinline__ void pair_body(const float4* __restrict__ spec, const
         xchg_bc_read_b(xl, v, t);
         dft16(v);                     // k1 -> n1   (role B)
         float2 tw1s[16];
-        if constexpr (!RESIDENT) {
+        {
             // TW1 re-read every pair (64 KiB per workgroup from L2); the pointer is laundered so
             // that the loads stay here, in flight across the exchange.
             const float4* twp = tw1_g;
@@ -231,7 +211,7 @@ __device__ __forceinline__ void pair_body(const float4* __restrict__ spec, const
         xchg_b_write(xl, v, t);       // into this half wave's own region: no barrier needed before
         __syncthreads();
         xchg_a_read(xl, v, t);
-        if constexpr (RESIDENT) mul_tw1(v, tw1r); else mul_tw1(v, tw1s);   // W_M^(u*k0) [* W_L^u odd]
+        mul_tw1(v, tw1s);             // W_M^(u*k0) [* W_L^u odd]
         dft16(v);                     // k0 -> n2   (role A): lane holds e[n] (p=0) or o[n]*W_L^u (p=1)
         if (p) {
 #pragma unroll
@@ -245,7 +225,7 @@ __device__ __forceinline__ void pair_body(const float4* __restrict__ spec, const
             const float ry = sgn * v[q].y + dpp_xor1(v[q].y);
             mag[q] = rx * rx + ry * ry;
         }
-        if constexpr (!RESIDENT) {
+        {
             if (it + 1 < it_end) {
                 pi = items[it + 1];
                 const float4* xi = spec + (wbase + pi.i) * (8 * kThreads);
@@ -365,7 +345,13 @@ __global__ __launch_bounds__(kThreads, 2) void k_pair_res(
     const float4* __restrict__ spec, const float4* __restrict__ tw1_g, const float2* __restrict__ tw2_g,
     const PairItem* __restrict__ items, const int* __restrict__ part_begin, int n_parts, int n_buoys, int n_pairs,
     int xcd_map, long first_window, float out_scale, int* __restrict__ lag_int, float* __restrict__ lag_frac,
-    float* __restrict__ peak, int dbg) {
+    float* __restrict__ peak, int dbg_rt) {
+#ifdef RMX_ABLATE
+    const int dbg = dbg_rt;   // timing-only ablation build (wrong results), as in k_win
+#else
+    constexpr int dbg = 0;
+    (void)dbg_rt;
+#endif
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2* xl = reinterpret_cast<float2*>(smem);
     float2* tw2_lds = reinterpret_cast<float2*>(smem + kLdsXchg);
@@ -982,16 +968,16 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
     spec, tw1_g, tw2_g, items, part_begin, n_parts, n_buoys, n_pairs, xcd_map, first_window, out_scale,      \
         lag_int, lag_frac, peak
 
-__global__ __launch_bounds__(kThreads, 4) void k_pair_str(RMX_PAIR_ARGS) { pair_body<false>(RMX_PAIR_PASS); }
+__global__ __launch_bounds__(kThreads, 4) void k_pair_str(RMX_PAIR_ARGS) { pair_body(RMX_PAIR_PASS); }
 
 
 // ---- CAF helpers --------------------------------------------------------------------------------
 // aug[w][b] = x[w][b], aug[w][B + b] = x[w][b] * rot[n]   (rot = exp(-2 pi i nu_d n) as complex64)
 template <bool U8>
 __global__ void k_caf_augment(const void* __restrict__ iq, const float2* __restrict__ rot, float2* __restrict__ aug,
-                              int n_buoys, int n_samples) {
+                              int n_buoys, int n_samples, long n_items) {
 #pragma clang fp contract(off)   // products and sums rounded one by one (and identically for both input types)
-    const long item = blockIdx.y;                       // w * B + b
+    for (long item = blockIdx.y; item < n_items; item += gridDim.y) {      // item = w * B + b (grid.y <= 65535)
     const long w = item / n_buoys, b = item % n_buoys;
     float2* o0 = aug + ((w * 2 * n_buoys) + b) * n_samples;
     float2* o1 = aug + ((w * 2 * n_buoys) + n_buoys + b) * n_samples;
@@ -1009,6 +995,7 @@ __global__ void k_caf_augment(const void* __restrict__ iq, const float2* __restr
         const float re = v.x * r.x - v.y * r.y;
         const float im = v.x * r.y + v.y * r.x;
         o1[n] = make_float2(re, im);
+    }
     }
 }
 __global__ void k_caf_select(int d, int n, const int* __restrict__ lag_d, const float* __restrict__ frac_d,
@@ -1639,8 +1626,12 @@ int rmx_set_option(rmx_ctx* c, const char* key, long value) {
         return RMX_OK;
     }
     if (!strcmp(key, "dbg")) {
+#ifdef RMX_ABLATE
         c->dbg = (int)value;
         return RMX_OK;
+#else
+        return fail(c, RMX_E_UNSUPPORTED, "option 'dbg' exists only in the -DRMX_ABLATE timing build");
+#endif
     }
     if (!strcmp(key, "fused")) {
         c->fused = value != 0;
@@ -1944,13 +1935,13 @@ int rmx_caf_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pair
     }
     const int items = n_windows * B;
     for (int d = 0; d < n_dopplers; ++d) {
-        const dim3 grid_aug((N + 255) / 256 > 64 ? 64 : (N + 255) / 256, items);
+        const dim3 grid_aug((N + 255) / 256 > 64 ? 64 : (N + 255) / 256, items > 65535 ? 65535 : items);
         if (u8)
             hipLaunchKernelGGL(k_caf_augment<true>, grid_aug, dim3(256), 0, c->stream, d_iq, c->caf_rot + (size_t)d * N,
-                               c->caf_aug, B, N);
+                               c->caf_aug, B, N, (long)items);
         else
             hipLaunchKernelGGL(k_caf_augment<false>, grid_aug, dim3(256), 0, c->stream, d_iq, c->caf_rot + (size_t)d * N,
-                               c->caf_aug, B, N);
+                               c->caf_aug, B, N, (long)items);
         RMX_HIP(c, hipGetLastError());
         const int rc = rmx_xcorr_batch(c->caf_child, c->caf_aug, n_windows, pl.data(), n_pairs, c->caf_lag, c->caf_frac,
                                        c->caf_peak, RMX_IN_DEVICE | RMX_OUT_DEVICE);

@@ -20,8 +20,10 @@ Same public names, argument meaning and error behaviour as the reference module 
 
 Without IQ on the detections every number equals the reference's (pinned by
 tests/golden/tdoa_conventions.json).  With IQ the lag comes from ``xcorr.XcorrEngine`` (HIP, gfx950);
-there is no CPU fallback: if IQ is supplied and the HIP library or a GPU is missing, the engine
-constructor raises (ImportError / RmxError) instead of silently degrading to timestamps.
+there is no CPU fallback and no silent degradation to timestamps: if IQ is supplied and the HIP library
+or a GPU is missing, the seam logs the engine's error on ``...TDoACalculator`` and yields no
+measurements (the reference's log-and-return convention, tdoa_processor.py:151-153);
+``TDoACalculator.measure_lags`` itself raises (ImportError / RmxError).
 """
 from __future__ import annotations
 
@@ -137,30 +139,50 @@ class GeodeticCalculator:
 # --------------------------------------------------------------------------------------------------
 class TDoACalculator:
     SPEED_OF_LIGHT = _C  # tdoa_processor.py:141
+    MAX_ENGINES = 4      # engines kept alive (one rmx_ctx each: device scratch), least recently used evicted
 
     def __init__(self, device: int = 0):
         self.logger = logging.getLogger(__name__ + ".TDoACalculator")
         self.device = device
-        self._engines: Dict[Tuple[int, int], Any] = {}
+        self._engines: Dict[Tuple[int, int], Any] = {}   # insertion order = recency
 
     # -- GPU engine cache ------------------------------------------------------------------------
     def _engine(self, n_buoys: int, n_samples: int, n_windows: int = 1):
         from . import xcorr  # raises ImportError loudly if the HIP library is not built
         key = (n_buoys, n_samples)
-        eng = self._engines.get(key)
+        eng = self._engines.pop(key, None)
         if eng is None or eng.max_windows < n_windows:
             if eng is not None:
                 eng.close()
             eng = xcorr.XcorrEngine(n_buoys, n_samples, max(n_windows, 1), device=self.device)
-            self._engines[key] = eng
+        self._engines[key] = eng                         # most recently used last
+        while len(self._engines) > self.MAX_ENGINES:
+            old = next(iter(self._engines))
+            self._engines.pop(old).close()
         return eng
 
+    def close(self):
+        for eng in self._engines.values():
+            eng.close()
+        self._engines.clear()
+
     def measure_lags(self, iq, pairs=None):
-        """Batched hot path: iq complex64 [W][B][N] (or uint8 [W][B][2N]) ->
-        (lag_int [W][P], lag_frac [W][P], peak [W][P]); lag = delay(j) - delay(i) in samples."""
+        """Batched hot path.  iq: complex64 [W][B][N] (or uint8 [W][B][2N]) ->
+        (lag_int [W][P], lag_frac [W][P], peak [W][P]); lag = delay(j) - delay(i) in samples.
+        A leading channel axis is a batch axis: [C][W][B][N] -> three [C][W][P] arrays (channels and
+        windows are independent units, tdoa_processor.py:363)."""
         iq = np.asarray(iq)
+        lead = None
+        if iq.ndim == 4:
+            lead = iq.shape[:2]
+            iq = iq.reshape((lead[0] * lead[1],) + iq.shape[2:])
+        if iq.ndim != 3:
+            raise ValueError(f"iq must be [W][B][N] or [C][W][B][N], got shape {iq.shape}")
         n = iq.shape[2] // 2 if iq.dtype == np.uint8 else iq.shape[2]
-        return self._engine(iq.shape[1], n, iq.shape[0]).correlate(iq, pairs)
+        out = self._engine(iq.shape[1], n, iq.shape[0]).correlate(iq, pairs)
+        if lead is not None:
+            out = tuple(a.reshape(lead + a.shape[1:]) for a in out)
+        return out
 
     @staticmethod
     def _iq_of(det: SignalDetection):
@@ -172,30 +194,65 @@ class TDoACalculator:
             return a
         return np.ascontiguousarray(a, dtype=np.complex64)
 
+    def _iq_batch_key(self, detections: Sequence[SignalDetection]):
+        """(key, stacked [B][N] windows) when every detection of the group carries an IQ window of one
+        shape, dtype and sample rate; (None, None) when none does; (False, None) when they disagree."""
+        iqs = [self._iq_of(d) for d in detections]
+        if all(a is None for a in iqs):
+            return None, None
+        if any(a is None for a in iqs):
+            self.logger.warning("Only some detections carry IQ windows; using time tags only")
+            return None, None
+        shapes = {(a.dtype.str, a.shape) for a in iqs}
+        rates = {float(d.sample_rate_hz) for d in detections}
+        if len(shapes) != 1 or len(rates) != 1:
+            self.logger.warning("IQ windows differ in length/dtype/sample rate; using time tags only")
+            return None, None
+        dt, shp = next(iter(shapes))
+        return (len(iqs), dt, shp, next(iter(rates))), np.stack(iqs)
+
+    def _measure_groups(self, stacked: np.ndarray):
+        """[G][B][N] -> lag [G][P] float64, or None after logging: the reference's seam never raises
+        (tdoa_processor.py:151-153) and there is no fallback to time tags once IQ was supplied."""
+        try:
+            li, lf, _ = self.measure_lags(stacked)
+            return li.astype(np.float64) + lf.astype(np.float64)
+        except Exception as e:   # RmxError (no device, bad shape), ImportError (library not built), ...
+            self.logger.error(f"Cross-correlation engine failed: {e}")
+            return None
+
     def _timing_confidence(self, b1: BuoyPosition, b2: BuoyPosition) -> float:
         # exp(-rss(timing accuracies) / 100 us), capped at 1 (tdoa_processor.py:200-210)
         return min(math.exp(-math.hypot(b1.timing_accuracy_ns, b2.timing_accuracy_ns) / 100000), 1.0)
 
     _calculate_timing_confidence = _timing_confidence  # reference's private name
 
+    _NO_LAG = object()
+
     def calculate_tdoa_measurements(self, detections: List[SignalDetection],
-                                    buoy_positions: Dict[str, BuoyPosition]) -> List[TDoAMeasurement]:
+                                    buoy_positions: Dict[str, BuoyPosition],
+                                    _lag=_NO_LAG) -> List[TDoAMeasurement]:
+        """The reference's pair loop (tdoa_processor.py:146-198).  `_lag` (private): this group's
+        [P] lags already measured in a batch with other groups by TDoAProcessor, or None when that batch
+        failed."""
         out: List[TDoAMeasurement] = []
         nd = len(detections)
         if nd < 2:
             self.logger.warning("Need at least 2 detections for TDoA calculation")
             return out
-        iqs = [self._iq_of(d) for d in detections]
         lag = None
-        if all(a is not None for a in iqs):
-            shapes = {(a.dtype.str, a.shape) for a in iqs}
-            rates = {float(d.sample_rate_hz) for d in detections}
-            if len(shapes) == 1 and len(rates) == 1:
-                li, lf, _ = self.measure_lags(np.stack(iqs)[None])
-                lag = li[0].astype(np.float64) + lf[0].astype(np.float64)
-                fs = rates.pop()
-            else:
-                self.logger.warning("IQ windows differ in length/dtype/sample rate; using time tags only")
+        fs = None
+        if _lag is self._NO_LAG:
+            key, stacked = self._iq_batch_key(detections)
+            if key:
+                res = self._measure_groups(stacked[None])
+                if res is None:
+                    return out
+                lag, fs = res[0], key[3]
+        elif _lag is None:
+            return out
+        else:
+            lag, fs = _lag, float(detections[0].sample_rate_hz)
         q = -1
         for i in range(nd):
             for j in range(i + 1, nd):
@@ -242,16 +299,24 @@ class HyperbolicPositioning:
                 return None
             pos = buoy_positions[b]
             xyz[b] = GeodeticCalculator.lat_lng_to_xyz(pos.lat, pos.lng, pos.altitude)
-        p1 = np.array([xyz[m.buoy1_id] for m in measurements])
-        p2 = np.array([xyz[m.buoy2_id] for m in measurements])
-        meas = np.array([m.distance_difference_m for m in measurements])
-        wgt = 1.0 / (np.array([m.confidence for m in measurements]) + 0.1)
+        # the objective in the reference's own scalar arithmetic (math.sqrt, one division per term,
+        # left-to-right sum: tdoa_processor.py:249-273): BFGS with finite-difference gradients stops on
+        # "precision loss" or not depending on the last bits of this function, so a vectorised sum
+        # (different rounding order) changes which calls return None
+        terms = [(xyz[m.buoy1_id], xyz[m.buoy2_id], m.distance_difference_m, m.confidence + 0.1)
+                 for m in measurements]
 
         def cost(tx):
-            d = np.linalg.norm(tx - p2, axis=1) - np.linalg.norm(tx - p1, axis=1)
-            return float(np.sum(wgt * (d - meas) ** 2))
+            x, y, z = tx
+            total = 0
+            for a, b, meas_m, den in terms:
+                d1 = math.sqrt((x - a[0]) ** 2 + (y - a[1]) ** 2 + (z - a[2]) ** 2)
+                d2 = math.sqrt((x - b[0]) ** 2 + (y - b[1]) ** 2 + (z - b[2]) ** 2)
+                total = total + ((d2 - d1) - meas_m) ** 2 / den
+            return total
 
-        x0 = np.mean(np.array(list(xyz.values())), axis=0)
+        pts = list(xyz.values())
+        x0 = [sum(q[k] for q in pts) / len(pts) for k in range(3)]
         try:
             import scipy.optimize
             res = scipy.optimize.minimize(cost, x0, method="BFGS", options={"maxiter": 1000})
@@ -326,14 +391,31 @@ class TDoAProcessor:
         if not detections:
             return []
         self.logger.info(f"Processing {len(detections)} signal detections")
-        results: List[TriangulationResult] = []
+        # frequency groups are independent units (tdoa_processor.py:363-377): all groups whose
+        # detections carry IQ windows of one shape go to the GPU as ONE [groups][B][N] batch
+        work = []
         for freq, group in self._group_by_frequency(detections).items():
             recent = self._filter_by_time_window(group)
             if len(recent) < self.min_buoys_for_triangulation:
                 self.logger.debug(f"Insufficient detections for {freq} MHz ({len(recent)} < "
                                   f"{self.min_buoys_for_triangulation})")
                 continue
-            meas = self.tdoa_calculator.calculate_tdoa_measurements(recent, self.buoy_positions)
+            key, stacked = self.tdoa_calculator._iq_batch_key(recent)
+            work.append([freq, recent, key, stacked, TDoACalculator._NO_LAG])
+        batches: Dict[Any, List[int]] = {}
+        for n, item in enumerate(work):
+            if item[2]:
+                batches.setdefault(item[2], []).append(n)
+        for key, members in batches.items():
+            lags = self.tdoa_calculator._measure_groups(np.stack([work[n][3] for n in members]))
+            for k, n in enumerate(members):
+                work[n][4] = None if lags is None else lags[k]
+        results: List[TriangulationResult] = []
+        for freq, recent, key, _, lag in work:
+            if key:
+                meas = self.tdoa_calculator.calculate_tdoa_measurements(recent, self.buoy_positions, _lag=lag)
+            else:
+                meas = self.tdoa_calculator.calculate_tdoa_measurements(recent, self.buoy_positions)
             if len(meas) < 2:
                 self.logger.debug(f"Insufficient TDoA measurements for {freq} MHz")
                 continue

@@ -149,12 +149,9 @@ class XcorrEngine:
         self._check(self._lib.rmx_last_timing(self._ctx, C.byref(f), C.byref(nf), C.byref(p), C.byref(npair)))
         return dict(fwd_ms=f.value, fwd_launches=nf.value, pair_ms=p.value, pair_launches=npair.value)
 
-    # -- the hot path ----------------------------------------------------------------------------
-    def correlate(self, iq: np.ndarray, pairs: Optional[np.ndarray] = None
-                  ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
-        """Host arrays in, host arrays out.  iq: complex64 [W][B][N] (or uint8 [W][B][2N] raw
-        rtl_sdr I,Q).  Returns (lag_int int32 [W][P], lag_frac float32 [W][P], peak float32 [W][P]);
-        lag = lag_int + lag_frac = delay(j) - delay(i) in samples."""
+    def _check_iq(self, iq):
+        """Shape/dtype check of a host window array before its pointer goes to C (which reads
+        n_windows * n_buoys * n_samples samples from it).  Returns (contiguous array, flags)."""
         iq = np.asarray(iq)
         flags = 0
         if iq.dtype == np.uint8:
@@ -165,7 +162,15 @@ class XcorrEngine:
             iq = np.ascontiguousarray(iq, dtype=np.complex64)
             if iq.ndim != 3 or iq.shape[1] != self.n_buoys or iq.shape[2] != self.n_samples:
                 raise ValueError(f"iq must be [W][{self.n_buoys}][{self.n_samples}], got {iq.shape}")
-        iq = np.ascontiguousarray(iq)
+        return np.ascontiguousarray(iq), flags
+
+    # -- the hot path ----------------------------------------------------------------------------
+    def correlate(self, iq: np.ndarray, pairs: Optional[np.ndarray] = None
+                  ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """Host arrays in, host arrays out.  iq: complex64 [W][B][N] (or uint8 [W][B][2N] raw
+        rtl_sdr I,Q).  Returns (lag_int int32 [W][P], lag_frac float32 [W][P], peak float32 [W][P]);
+        lag = lag_int + lag_frac = delay(j) - delay(i) in samples."""
+        iq, flags = self._check_iq(iq)
         W = iq.shape[0]
         if pairs is not None:
             pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
@@ -189,13 +194,7 @@ class XcorrEngine:
         """Cross-ambiguity search (rmx_caf_batch): host arrays in and out.  doppler_cps: hypotheses in
         cycles/sample.  Returns (doppler_idx int32, lag_int int32, lag_frac float32, peak float32),
         each [W][P]."""
-        iq = np.asarray(iq)
-        flags = 0
-        if iq.dtype == np.uint8:
-            flags |= RMX_IN_U8
-        else:
-            iq = np.ascontiguousarray(iq, dtype=np.complex64)
-        iq = np.ascontiguousarray(iq)
+        iq, flags = self._check_iq(iq)
         W = iq.shape[0]
         if pairs is not None:
             pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
@@ -204,7 +203,7 @@ class XcorrEngine:
         else:
             P = self.n_buoys * (self.n_buoys - 1) // 2
             pp = None
-        dc = np.ascontiguousarray(doppler_cps, dtype=np.float64)
+        dc = np.ascontiguousarray(doppler_cps, dtype=np.float64).reshape(-1)
         dop = np.zeros((W, P), np.int32)
         lag_int = np.zeros((W, P), np.int32)
         lag_frac = np.zeros((W, P), np.float32)
@@ -276,6 +275,24 @@ class XcorrEngine:
             n = min(int(cnt[w]), max_peaks)
             out.append((bins[w, :n].copy(), pw[w, :n].copy(), snr[w, :n].copy(), conf[w, :n].copy(), float(floor[w])))
         return out
+
+    def caf_device(self, iq_ptr: int, n_windows: int, doppler_cps, dop_ptr: int, lag_int_ptr: int,
+                   lag_frac_ptr: int, peak_ptr: int, pairs: Optional[np.ndarray] = None, u8: bool = False):
+        """rmx_caf_batch with device pointers in and out (the Doppler grid and the pair list stay host
+        arrays); asynchronous on the ctx stream."""
+        if pairs is not None:
+            pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+            P = pairs.shape[0]
+            pp = pairs.ctypes.data_as(C.c_void_p)
+        else:
+            P = self.n_buoys * (self.n_buoys - 1) // 2
+            pp = None
+        dc = np.ascontiguousarray(doppler_cps, dtype=np.float64).reshape(-1)
+        flags = RMX_IN_DEVICE | RMX_OUT_DEVICE | (RMX_IN_U8 if u8 else 0)
+        self._check(self._lib.rmx_caf_batch(self._ctx, C.c_void_p(iq_ptr), n_windows, pp, P,
+                                            dc.ctypes.data_as(C.c_void_p), dc.shape[0], C.c_void_p(dop_ptr),
+                                            C.c_void_p(lag_int_ptr), C.c_void_p(lag_frac_ptr), C.c_void_p(peak_ptr),
+                                            flags))
 
     def correlate_device(self, iq_ptr: int, n_windows: int, lag_int_ptr: int, lag_frac_ptr: int,
                          peak_ptr: int, pairs: Optional[np.ndarray] = None, u8: bool = False):

@@ -15,6 +15,8 @@ It imports ``/root/reference/tdoa_processor.py`` and records
   uint8 I/Q that decodes to them); large cases store the generator seed + an input checksum.
 * ``caf_*.npz`` -- the same primitive over a Doppler grid (``run_caf_case``); ``--caf-only``
   regenerates just these.
+* ``triangulate_position.json`` -- ``HyperbolicPositioning.triangulate_position`` on deterministic
+  scenarios (``make_triangulation``); ``--tri-only`` regenerates just this.
 * ``tdoa_conventions.json`` -- ``TDoACalculator.calculate_tdoa_measurements`` on the hand-built
   detections of the reference's own ``main()`` example (``tdoa_processor.py:475-490``): pins the
   pair order, the sign (buoy2 - buoy1) and the ns -> metres conversion.
@@ -115,6 +117,11 @@ def make_caf(ref):
          [0, 1, -2]),
         ("caf_b3_n1024", dict(n_windows=2, n_buoys=3, n_samples=1024, sample_rate_hz=2.4e6, seed=22), 7, 0.5,
          [1, -1, 2]),
+        # BASELINE configs[4]'s grid: 21 hypotheses (+-500 Hz step 50 Hz at 20 MS/s = +-10 steps), small window;
+        # the step is 0.25 bin of this window, so neighbouring hypotheses overlap as they do at N = 2^18
+        # (50 Hz = 0.66 bin of 76 Hz): the winner is decided by the peak heights, not by orthogonality
+        ("caf_b4_n2048_d21", dict(n_windows=1, n_buoys=4, n_samples=2048, sample_rate_hz=20e6, seed=23), 21, 0.25,
+         [0, 5, -4, 2]),
     ]
     for name, kw, nd, step_bins, offs in cases:
         step = step_bins / kw["n_samples"]                     # cycles/sample
@@ -126,6 +133,60 @@ def make_caf(ref):
         print(name, "dop", res["dop_idx"].tolist(), "lag", res["lag_int"].tolist())
 
 
+TRI_SCENARIOS = {
+    # name: (buoys (id, lat, lng, altitude, timing_accuracy_ns), transmitter (lat, lng, alt), range noise sigma [m])
+    "square4": ([("A", 35.40, -97.60, 0.0, 50000), ("B", 35.40, -97.40, 0.0, 50000), ("C", 35.55, -97.40, 0.0, 50000),
+                 ("D", 35.55, -97.60, 0.0, 50000)], (35.47, -97.52, 0.0), 0.0),
+    "penta5": ([("A", 51.50, -0.20, 0.0, 50000), ("B", 51.42, -0.05, 10.0, 50000), ("C", 51.50, 0.10, 0.0, 50000),
+                ("D", 51.60, 0.02, 5.0, 50000), ("E", 51.60, -0.15, 0.0, 50000)], (51.52, -0.06, 0.0), 0.0),
+    "tri3": ([("A", 51.505, -0.09, 0.0, 50000), ("B", 51.51, -0.1, 0.0, 75000), ("C", 51.5, -0.12, 0.0, 60000)],
+             (51.507, -0.1, 0.0), 0.0),
+    "tri3_noisy": ([("A", 51.505, -0.09, 0.0, 50000), ("B", 51.51, -0.1, 0.0, 75000), ("C", 51.5, -0.12, 0.0, 60000)],
+                   (51.507, -0.1, 0.0), 5.0),
+    "hex6alt": ([("A", 10.0, 20.0, 0.0, 1000), ("B", 10.05, 20.08, 50.0, 1000), ("C", 10.12, 20.08, 0.0, 1000),
+                 ("D", 10.17, 20.0, 30.0, 1000), ("E", 10.12, 19.92, 0.0, 1000), ("F", 10.05, 19.92, 80.0, 1000)],
+                (10.09, 20.01, 0.0), 0.0),
+    "penta5_noisy": ([("A", 51.50, -0.20, 0.0, 50000), ("B", 51.42, -0.05, 10.0, 50000), ("C", 51.50, 0.10, 0.0, 50000),
+                      ("D", 51.60, 0.02, 5.0, 50000), ("E", 51.60, -0.15, 0.0, 50000)], (51.52, -0.06, 0.0), 5.0),
+}
+
+
+def make_triangulation(ref):
+    """``HyperbolicPositioning.triangulate_position`` (tdoa_processor.py:218-328) of the imported reference
+    on deterministic scenarios: exact (or seeded-noisy) distance differences of a known transmitter for
+    every pair i<j.  Records the reference's result (or null where its BFGS reports failure) -- the
+    consumer row a8 and the cost bar of the batched GPU solve are pinned to these numbers."""
+    G = ref.GeodeticCalculator
+    out = {}
+    for name, (buoys, tx, sigma) in TRI_SCENARIOS.items():
+        rng = np.random.default_rng(3)
+        pos = {b[0]: ref.BuoyPosition(*b) for b in buoys}
+        xyz = {b[0]: np.array(G.lat_lng_to_xyz(b[1], b[2], b[3])) for b in buoys}
+        t = np.array(G.lat_lng_to_xyz(*tx))
+        meas = []
+        ids = [b[0] for b in buoys]
+        for i in range(len(ids)):
+            for j in range(i + 1, len(ids)):
+                dd = float(np.linalg.norm(t - xyz[ids[j]]) - np.linalg.norm(t - xyz[ids[i]]))
+                if sigma:
+                    dd += float(rng.normal(0.0, sigma))
+                meas.append([ids[i], ids[j], int(round(dd / 299792458.0 * 1e9)), dd, 0.8, 121.5])
+        res = ref.HyperbolicPositioning().triangulate_position([ref.TDoAMeasurement(*m) for m in meas], pos)
+        out[name] = dict(buoys=[list(b) for b in buoys], transmitter=list(tx), sigma_m=sigma, measurements=meas,
+                         result=None if res is None else dict(
+                             estimated_lat=res.estimated_lat, estimated_lng=res.estimated_lng,
+                             estimated_altitude=res.estimated_altitude, accuracy_meters=res.accuracy_meters,
+                             confidence=res.confidence, frequency_mhz=res.frequency_mhz, method=res.method,
+                             contributing_buoys=sorted(res.contributing_buoys),
+                             cost=res.accuracy_meters ** 2 * len(meas)))
+        print(name, None if res is None else (res.estimated_lat, res.estimated_lng, res.accuracy_meters))
+    import scipy
+    with open(os.path.join(HERE, "triangulate_position.json"), "w") as f:
+        json.dump(dict(meta=dict(numpy=np.__version__, scipy=scipy.__version__,
+                                 source="HyperbolicPositioning.triangulate_position of /root/reference/tdoa_processor.py"),
+                       scenarios=out), f, indent=1)
+
+
 def checksum(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
@@ -134,6 +195,9 @@ def main():
     ref = load_reference()
     if "--caf-only" in sys.argv:
         make_caf(ref)
+        return
+    if "--tri-only" in sys.argv:
+        make_triangulation(ref)
         return
     import scipy
     meta = dict(numpy=np.__version__, scipy=scipy.__version__,
@@ -172,6 +236,7 @@ def main():
     print("edge lags", res["lag_int"].ravel(), res["lag_frac"].ravel())
 
     make_caf(ref)
+    make_triangulation(ref)
 
     # large, seed-regenerated cases (inputs not stored)
     large = [

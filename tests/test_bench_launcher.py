@@ -1,0 +1,50 @@
+"""bench.py --gpus N starts its own N ranks.  CPU: the ranks rendezvous over gloo,
+take their window blocks and rank 0 gathers; no compute (--launch-check), so no GPU is needed."""
+import json
+import os
+import subprocess
+import sys
+
+from conftest import ROOT
+
+
+def _run(args, env_extra=None):
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True,
+                          text=True, timeout=300)
+
+
+def _json_line(out):
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out
+    return json.loads(lines[0])
+
+
+def test_gpus_2_spawns_two_ranks():
+    r = _run(["--gpus", "2", "--launch-check"])
+    assert r.returncode == 0, r.stderr
+    line = _json_line(r.stdout)
+    assert line == {"launch_check": True, "n_gpus": 2, "ranks_seen": 2, "backend": "gloo"}
+
+
+def test_single_rank_needs_no_launcher():
+    r = _run(["--launch-check"])
+    assert r.returncode == 0, r.stderr
+    assert _json_line(r.stdout)["n_gpus"] == 1
+
+
+def test_gpus_must_match_world_size():
+    # under an external launcher --gpus has to agree with WORLD_SIZE: a silent 1-GPU run is refused
+    r = _run(["--gpus", "4", "--launch-check"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode == 2 and "WORLD_SIZE=2" in r.stderr
+
+
+def test_parent_does_not_import_torch_before_spawning():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    head = src[:src.index("def launch_ranks")]
+    assert "import torch" not in head and "import numpy" not in head
+    body = src[src.index("def main()"):]
+    assert body.index("launch_ranks(args.gpus") < body.index("import torch")

@@ -79,6 +79,15 @@ def test_edge_cases_n256_fixture(xc, golden_dir):
     assert lf[2, 0] == 0.0 and lf[3, 0] == 0.0
     assert li[4, 0] in (-7, 9) and li[5, 0] == 0
     assert np.allclose(pk[1:], g["peak"][1:], rtol=1e-5)
+    # fractional lag of every window against the reference-generated values (windows 0, 2, 3: exactly 0
+    # by the edge / flat-top rule; 1, 4: isolated impulses, the neighbour taps are round-off of a peak of
+    # height 1..2 -> |frac| ~ 1e-8; 5: the flat triangular top, conditioned as in test_edge_cases_n4096)
+    ref = g["lag_frac"]
+    assert lf[0, 0] == ref[0, 0] == 0.0
+    for w in (1, 2, 3, 4):
+        assert abs(lf[w, 0] - ref[w, 0]) <= TOL, (w, lf[w, 0], ref[w, 0])
+    cond = n / 2.0
+    assert abs(lf[5, 0] - ref[5, 0]) <= max(TOL, 4 * 6e-8 * cond)
 
 
 @pytest.mark.parametrize("name", ["xcorr_cfg1_n262144", "xcorr_b3_n1048576"])
@@ -120,6 +129,36 @@ def test_edge_cases_n4096(xc):
     cond = float(rp[5, 0]) / abs(2.0 * float(rp[5, 0]) / N)
     assert li[5, 0] == ri[5, 0] == 0 and abs(lf[5, 0] - rf[5, 0]) <= max(TOL, 4 * 6e-8 * cond)
     assert np.allclose(pk[1:], rp[1:], rtol=1e-5)
+
+
+def test_exact_tie_resolves_to_lowest_index(xc):
+    """numpy's argmax rule (ties -> lowest 'full' index, i.e. the most negative lag) on a tie that the
+    HIP transform reproduces EXACTLY, so the rule is tested rather than the rounding.
+
+    x_i = d[0] + d[N/2],  x_j = d[a] - d[a + N/2]  (d = unit impulse, a < N/2).  The true correlation
+    has its two peaks at lags a - N/2 (+1) and a + N/2 (-1), N apart, and cancels at lag a.  In the
+    kernel every even bin of the 2N-point product is an exact zero (the N-point spectrum of x_i is 2 on
+    even and exactly 0 on odd bins, that of x_j exactly 0 on even bins: the butterflies only add and
+    subtract equal values there, twiddles multiply zeros), so the even half-transform e[n] is exactly 0
+    and the last radix-2 gives r[n] = +o[n], r[n + N] = -o[n]: the two peaks have bit-identical
+    magnitudes.  The lower 'full' index, lag a - N/2, must win, with the same peak value either way;
+    the all-pairs kernel and the custom-pair kernels (same FFT blocks) agree."""
+    N = 4096
+    for a in (5, 777, 2047):
+        e = np.zeros((1, 2, N), np.complex64)
+        e[0, 0, 0] = 1.0; e[0, 0, N // 2] = 1.0
+        e[0, 1, a] = 1.0; e[0, 1, a + N // 2] = -1.0
+        ri, rf, rp = orc.xcorr_batch_literal(e)
+        assert ri[0, 0] in (a - N // 2, a + N // 2)              # the oracle's FFT decides its own tie by rounding
+        with xc.XcorrEngine(2, N, 1) as eng:
+            li, lf, pk = eng.correlate(e)
+            lc, fc, pc = eng.correlate(e, pairs=np.array([[0, 1], [1, 0]], np.int32))
+        assert li[0, 0] == a - N // 2, (a, li)
+        assert lc[0, 0] == a - N // 2
+        # reversed pair: peaks at -(a - N/2) and -(a + N/2); the lower index is -(a + N/2)
+        assert lc[0, 1] == -(a + N // 2)
+        assert abs(pk[0, 0] - 1.0) < 1e-5 and pk[0, 0] == pc[0, 0] == pc[0, 1]
+        assert abs(lf[0, 0]) <= TOL
 
 
 def test_custom_pairs_and_antisymmetry(xc):
@@ -229,7 +268,7 @@ def test_tdoa_processor_with_iq(xc):
         assert abs(m.distance_difference_m - m.time_difference_ns / 1e9 * 299792458.0) < 1e-9
 
 
-@pytest.mark.parametrize("name", ["caf_b3_n4096", "caf_b3_n1024"])
+@pytest.mark.parametrize("name", ["caf_b3_n4096", "caf_b3_n1024", "caf_b4_n2048_d21"])
 def test_caf_golden(xc, golden_dir, name):
     """rmx_caf_batch against the Doppler-grid fixtures generated with the reference primitive:
     winning hypothesis and integer lag exact, fractional lag / peak to 1e-5; per-bin peaks of the
@@ -323,6 +362,11 @@ def test_error_codes_on_device(xc):
             eng.caf(iq[:2], [])                                  # empty Doppler grid
         with pytest.raises(xc.RmxError):
             eng.set_option("no_such_option", 1)
+        with pytest.raises(xc.RmxError) as e:
+            eng.set_option("dbg", 2)                             # ablation masks exist only under -DRMX_ABLATE
+        assert e.value.code == -5
+        with pytest.raises(ValueError):
+            eng.caf(np.zeros((2, 4, 4096), np.complex64), [0.0])  # wrong buoy count: refused before C reads it
         with pytest.raises(xc.RmxError):
             eng.solve(np.zeros((3, 3)), np.zeros((2, 3), np.int32), np.zeros((2, 3), np.float32), 0.0)   # fs = 0
         # the engine is still usable after errors
@@ -397,6 +441,30 @@ def test_cfg5_shape_ground_truth(xc):
     assert np.all(np.abs(li + lf - true) < 1.0)
     rel = np.rint((offs[pairs[:, 1]] - offs[pairs[:, 0]]) / step).astype(int) + D // 2     # in 0..4
     assert np.array_equal(dop[0], rel)
+
+
+def test_cfg5_full_doppler_grid(xc):
+    """BASELINE configs[4] as stated: 32 buoys (496 pairs), N = 262144 at 20 MS/s, the whole +-500 Hz
+    grid in 50 Hz steps (21 hypotheses), one of a GPU's 8 windows.  Ground truth for every pair (lag
+    within a sample, Doppler bin exact for on-grid offsets) and the oracle on four pairs."""
+    B, N, fs, D = 32, 262144, 20e6, 21
+    step = 50.0 / fs
+    grid = (np.arange(D) - D // 2) * step
+    rng = np.random.default_rng(6)
+    offs = rng.integers(-5, 6, size=B) * step              # per-buoy Doppler in +-250 Hz: pairs within +-500 Hz
+    iq, delays = rm.synth.make_windows(1, B, N, fs, seed=1005, doppler_cps=offs)
+    with xc.XcorrEngine(B, N, 1) as eng:
+        dop, li, lf, pk = eng.caf(iq, grid)
+    pairs = orc.pair_list(B)
+    true = delays[:, pairs[:, 1]] - delays[:, pairs[:, 0]]
+    assert np.all(np.abs(li + lf - true) < 1.0)
+    rel = np.rint((offs[pairs[:, 1]] - offs[pairs[:, 0]]) / step).astype(int) + D // 2
+    assert rel.min() >= 0 and rel.max() <= D - 1
+    assert np.array_equal(dop[0], rel)
+    sel = np.array([0, 100, 300, 495])
+    rd, ri, rf, rp = orc.caf_batch(iq, grid, pairs[sel])
+    assert np.array_equal(dop[:, sel], rd)
+    _assert_parity(li[:, sel], lf[:, sel], pk[:, sel], ri, rf, rp)
 
 
 def test_cfg2_full_size_properties(xc):

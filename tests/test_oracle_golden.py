@@ -93,7 +93,7 @@ def test_decode_u8_matches_reference_decode():
     assert z.dtype == np.complex64 and z[0] == np.complex64(-127.5 - 126.5j) and z[-1] == np.complex64(126.5 + 127.5j)
 
 
-@pytest.mark.parametrize("name", ["caf_b3_n4096", "caf_b3_n1024"])
+@pytest.mark.parametrize("name", ["caf_b3_n4096", "caf_b3_n1024", "caf_b4_n2048_d21"])
 def test_caf_oracle_matches_reference_outputs(golden_dir, name):
     """Cross-ambiguity (S8): the oracle's per-bin call is the reference primitive on the de-rotated
     window, so the reduction over (d, lag) is bit-identical to the fixture."""

@@ -53,6 +53,69 @@ def test_oracle_objective_is_the_reference_objective():
     assert abs(sr.cost(p0, b1, b2, d, w) - ref) <= 1e-9 * ref
 
 
+def _tri_scenarios():
+    import json
+    import os
+    from conftest import GOLDEN
+    return json.load(open(os.path.join(GOLDEN, "triangulate_position.json")))["scenarios"]
+
+
+def _tri_arrays(sc):
+    ids = [b[0] for b in sc["buoys"]]
+    buoys = np.array([G.lat_lng_to_xyz(b[1], b[2], b[3]) for b in sc["buoys"]])
+    pairs = np.array([(ids.index(m[0]), ids.index(m[1])) for m in sc["measurements"]], np.int32)
+    d = np.array([[m[3] for m in sc["measurements"]]], np.float64)
+    w = np.array([[1.0 / (m[4] + 0.1) for m in sc["measurements"]]], np.float64)
+    return buoys, pairs, d, w
+
+
+@pytest.mark.parametrize("name", ["square4", "penta5", "tri3", "tri3_noisy", "hex6alt", "penta5_noisy"])
+def test_oracle_cost_not_above_the_reference_bfgs(name):
+    """Row f3 pinned to the reference: on the measurements of tests/golden/triangulate_position.json the
+    Levenberg-Marquardt rule reaches a cost <= the cost the imported reference's BFGS stopped at
+    (tdoa_processor.py:281-300; cost = accuracy_meters^2 * len(measurements)), and the same horizontal
+    fix.  Where the reference's BFGS reported failure (result null) LM still has to reach the noise
+    level."""
+    sc = _tri_scenarios()[name]
+    buoys, pairs, d, w = _tri_arrays(sc)
+    pos, fmin, iters = sr.solve_batch(buoys, pairs, d, w)
+    ref = sc["result"]
+    P = len(pairs)
+    if ref is not None:
+        assert fmin[0] <= ref["cost"] * (1 + 1e-9) + 1e-6
+        if len(buoys) >= 4:      # three buoys leave a curve of equal-cost positions in 3-D: only the cost is comparable
+            lat, lng, _ = G.xyz_to_lat_lng(*pos[0])
+            assert abs(lat - ref["estimated_lat"]) < 2e-6 and abs(lng - ref["estimated_lng"]) < 2e-6
+    else:
+        assert fmin[0] < 20.0 * w.max() * P * max(sc["sigma_m"], 0.02) ** 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["square4", "penta5", "tri3", "tri3_noisy", "hex6alt", "penta5_noisy"])
+def test_gpu_solve_cost_not_above_the_reference_bfgs(name):
+    import __graft_entry__ as g
+    g.build()
+    from radio_mapper_amd import xcorr
+    sc = _tri_scenarios()[name]
+    buoys, pairs, d, w = _tri_arrays(sc)
+    fs = 10e6
+    lag = d / sr.SPEED_OF_LIGHT * fs                       # metres -> samples (float32 frac: ~1e-3 m)
+    li = np.round(lag).astype(np.int32)
+    lf = (lag - li).astype(np.float32)
+    with xcorr.XcorrEngine(len(buoys), 4096, 1) as eng:
+        pos, f, it = eng.solve(buoys, li, lf, fs, weight=w.astype(np.float32), pairs=pairs)
+    ref = sc["result"]
+    if ref is not None:
+        # the lag grid quantises the measurements by <= 1e-3 m: allow that much slack in the cost
+        slack = 2.0 * w.max() * len(pairs) * (np.sqrt(max(ref["cost"], 0) / len(pairs)) * 2e-3 + 4e-6)
+        assert f[0] <= ref["cost"] + slack
+        if len(buoys) >= 4:
+            lat, lng, _ = G.xyz_to_lat_lng(*pos[0])
+            assert abs(lat - ref["estimated_lat"]) < 2e-6 and abs(lng - ref["estimated_lng"]) < 2e-6
+    else:
+        assert f[0] < 20.0 * w.max() * len(pairs) * max(sc["sigma_m"], 0.02) ** 2
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("n_buoys,noise_m", [(4, 0.0), (5, 3.0), (8, 10.0), (16, 5.0)])
 def test_gpu_solve_matches_oracle(n_buoys, noise_m):

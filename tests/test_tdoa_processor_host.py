@@ -87,3 +87,129 @@ def test_window_shard_partitions():
             pos += c
     with pytest.raises(ValueError):
         window_shard(4, 2, 2)
+
+
+def _iq_dets(conv, freq, n=64, fs=2.4e6, seed=0):
+    rng = np.random.default_rng(seed)
+    base = conv["detections"][0][4]
+    out = []
+    for k, b in enumerate(conv["buoys"]):
+        iq = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+        out.append(tp.SignalDetection(b[0], freq, -50, "t", base + 1000 * k, b[1], b[2], 0.9, "beacon", iq, fs))
+    return out
+
+
+def test_iq_groups_go_to_the_engine_as_one_batch(conv, monkeypatch):
+    """Three frequency groups with IQ windows of one shape -> ONE measure_lags call with [3][B][N]
+    (tdoa_processor.py:363-377 loops the groups one by one; here they are one GPU batch)."""
+    p = _proc(conv)
+    calls = []
+
+    def fake(iq, pairs=None):
+        iq = np.asarray(iq)
+        calls.append(iq.shape)
+        W, B = iq.shape[:2]
+        P = B * (B - 1) // 2
+        li = np.arange(W * P, dtype=np.int32).reshape(W, P)          # lag q of group w = w*P + q samples
+        return li, np.zeros((W, P), np.float32), np.ones((W, P), np.float32)
+
+    monkeypatch.setattr(p.tdoa_calculator, "measure_lags", fake)
+    dets = _iq_dets(conv, 121.5, seed=1) + _iq_dets(conv, 156.8, seed=2) + _iq_dets(conv, 243.0, seed=3)
+    groups = {}
+    orig = p.hyperbolic_positioner.triangulate_position
+
+    def spy(meas, pos):
+        groups[meas[0].frequency_mhz] = [m.time_difference_ns for m in meas]
+        return orig(meas, pos)
+
+    monkeypatch.setattr(p.hyperbolic_positioner, "triangulate_position", spy)
+    p.process_signal_detections(dets)
+    assert calls == [(3, 3, 64)]
+    fs = 2.4e6
+    for g, f in enumerate([121.5, 156.8, 243.0]):
+        # window-start difference (1000 ns per buoy index) + round(lag / fs * 1e9), pair order (0,1),(0,2),(1,2)
+        want = [1000 * (j - i) + int(round((g * 3 + q) / fs * 1e9)) for q, (i, j) in enumerate([(0, 1), (0, 2), (1, 2)])]
+        assert groups[f] == want
+
+
+def test_engine_failure_is_logged_not_raised(conv, caplog):
+    """With IQ on the detections and no usable engine the seam logs on ...TDoACalculator and yields
+    nothing: it neither raises (tdoa_processor.py:151-153) nor falls back to the time tags."""
+    from radio_mapper_amd import xcorr
+    if xcorr.device_count() > 0:
+        pytest.skip("a GPU is visible: the engine works")
+    p = _proc(conv)
+    dets = _iq_dets(conv, 121.5)
+    with caplog.at_level("ERROR"):
+        assert p.tdoa_calculator.calculate_tdoa_measurements(dets, p.buoy_positions) == []
+        assert p.process_signal_detections(dets) == []
+        assert p.triangulate_signal(dets) is None
+    assert any("engine failed" in r.message and r.name.endswith("TDoACalculator") for r in caplog.records)
+    with pytest.raises(Exception):
+        p.tdoa_calculator.measure_lags(np.stack([d.iq_samples for d in dets])[None])   # the engine entry itself raises
+
+
+def test_measure_lags_channel_axis_and_engine_cache(monkeypatch):
+    calc = tp.TDoACalculator()
+    made = []
+
+    class FakeEngine:
+        def __init__(self, nb, ns, mw):
+            self.max_windows, self.closed = mw, False
+            made.append(self)
+
+        def correlate(self, iq, pairs=None):
+            W, B = iq.shape[:2]
+            P = B * (B - 1) // 2
+            return (np.arange(W * P, dtype=np.int32).reshape(W, P), np.zeros((W, P), np.float32),
+                    np.zeros((W, P), np.float32))
+
+        def close(self):
+            self.closed = True
+
+    import radio_mapper_amd.xcorr as xc
+    monkeypatch.setattr(xc, "XcorrEngine", lambda nb, ns, mw, device=0: FakeEngine(nb, ns, mw))
+    li, lf, pk = calc.measure_lags(np.zeros((2, 5, 3, 32), np.complex64))       # [C][W][B][N]
+    assert li.shape == lf.shape == pk.shape == (2, 5, 3)
+    assert np.array_equal(li.reshape(10, 3), np.arange(30).reshape(10, 3))
+    with pytest.raises(ValueError):
+        calc.measure_lags(np.zeros((3, 32), np.complex64))
+    for n in (64, 128, 256, 512, 1024):                                          # five more shapes: LRU of 4
+        calc.measure_lags(np.zeros((1, 3, n), np.complex64))
+    assert len(calc._engines) == tp.TDoACalculator.MAX_ENGINES
+    assert made[0].closed and made[1].closed and not made[-1].closed
+    calc.close()
+    assert all(e.closed for e in made)
+
+
+@pytest.fixture(scope="module")
+def tri(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "triangulate_position.json")))["scenarios"]
+
+
+@pytest.mark.parametrize("name", ["square4", "penta5", "tri3", "tri3_noisy", "hex6alt", "penta5_noisy"])
+def test_triangulate_position_against_reference_results(tri, name):
+    """Row a8: HyperbolicPositioning.triangulate_position against the results the imported reference
+    produced on the same measurements (tests/golden/make_golden.py:make_triangulation).  The
+    horizontal fix and the accuracy figure are what the reference determines; its altitude wanders by
+    metres along the unobserved vertical (BFGS stops where the gradient is flat), so that field is
+    only held to 100 m."""
+    sc = tri[name]
+    pos = {b[0]: tp.BuoyPosition(*b) for b in sc["buoys"]}
+    meas = [tp.TDoAMeasurement(*m) for m in sc["measurements"]]
+    got = tp.HyperbolicPositioning().triangulate_position(meas, pos)
+    want = sc["result"]
+    if want is None:                     # the reference's BFGS reported failure -> None, no exception
+        assert got is None
+        return
+    assert got is not None
+    assert abs(got.estimated_lat - want["estimated_lat"]) < 2e-6          # 0.2 m
+    assert abs(got.estimated_lng - want["estimated_lng"]) < 2e-6
+    assert abs(got.estimated_altitude - want["estimated_altitude"]) < 100.0
+    assert abs(got.accuracy_meters - want["accuracy_meters"]) <= 1e-3 + 1e-4 * want["accuracy_meters"]
+    assert got.confidence == pytest.approx(want["confidence"], rel=1e-12)
+    assert got.frequency_mhz == want["frequency_mhz"] and got.method == want["method"]
+    assert sorted(got.contributing_buoys) == want["contributing_buoys"]
+    # and the fix is the transmitter the scenario was built from (noise-free cases: centimetres)
+    _, dist = tp.GeodeticCalculator.bearing_distance(got.estimated_lat, got.estimated_lng, *sc["transmitter"][:2])
+    assert dist < (0.05 if sc["sigma_m"] == 0 else 10 * sc["sigma_m"])
