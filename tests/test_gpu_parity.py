@@ -157,7 +157,7 @@ def test_exact_tie_resolves_to_lowest_index(xc):
         assert lc[0, 0] == a - N // 2
         # reversed pair: peaks at -(a - N/2) and -(a + N/2); the lower index is -(a + N/2)
         assert lc[0, 1] == -(a + N // 2)
-        assert abs(pk[0, 0] - 1.0) < 1e-5 and pk[0, 0] == pc[0, 0] == pc[0, 1]
+        assert abs(pk[0, 0] - 1.0) < 1e-5 and abs(pc[0, 0] - 1.0) < 1e-5 and pc[0, 0] == pc[0, 1]
         assert abs(lf[0, 0]) <= TOL
 
 
