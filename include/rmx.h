@@ -79,7 +79,10 @@ int rmx_set_stream(rmx_ctx* ctx, void* hip_stream);
 /* Tuning knobs (all optional): "chunk_windows" (windows per launch), "timing" (1: bracket every
  * launch with HIP events, read back with rmx_last_timing), "fused" (default 1; 0 forces the separate
  * forward + pair kernels that custom pair lists use), "resident" and "pairs_per_block" (variants of
- * that unfused pair kernel), "dbg" (ablation masks of the -DRMX_ABLATE timing build; every other build
+ * that unfused pair kernel), "win8" / "pk" (1: run the fused N = 4096 path on k_win8 -- 8 points x 1024
+ * threads, 4 waves per SIMD -- or on k_winp -- k_win on packed fp32 -- instead of k_win; same results to
+ * rounding, measured slower: DESIGN.md section 6), "stag" (0..4, k_win8's half-order staggering),
+ * "dbg" (ablation masks of the -DRMX_ABLATE timing build; every other build
  * rejects the key with RMX_E_UNSUPPORTED and compiles the masks out of all kernels).
  * Returns RMX_E_INVAL for an unknown key. */
 int rmx_set_option(rmx_ctx* ctx, const char* key, long value);

@@ -25,6 +25,8 @@
 
 #include "../../include/rmx.h"
 #include "fft_r16.hpp"
+#include "win8.hpp"
+#include "winpk.hpp"
 #include "generic_path.hpp"
 #include "detect_path.hpp"
 
@@ -959,6 +961,20 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
     }   // next window of this workgroup
 }
 
+// k_win on packed fp32 (winpk.hpp): same protocol, same resolve routine
+template <bool U8>
+__global__ __launch_bounds__(kThreads, 2) void k_winp(const void* __restrict__ iq_v, float4* __restrict__ spec,
+                                                      const float4* __restrict__ tw1_g,
+                                                      const float2* __restrict__ tw2_g, int n_buoys,
+                                                      long first_window, float out_scale, int* __restrict__ lag_int,
+                                                      float* __restrict__ lag_frac, float* __restrict__ peak, int n_win) {
+    pk::winp_body<U8>(iq_v, spec, tw1_g, tw2_g, n_buoys, first_window, out_scale, lag_int, lag_frac, peak, n_win,
+                      [](int lane, const float4* red, const float* halo, const int* oidx, int first, int cnt, long obase,
+                         float osc, int* li, float* lf, float* pk_) __attribute__((always_inline)) {
+                          resolve_batch(lane, red, halo, oidx, first, cnt, obase, osc, li, lf, pk_);
+                      });
+}
+
 #define RMX_PAIR_ARGS                                                                                         \
     const float4 *__restrict__ spec, const float4 *__restrict__ tw1_g, const float2 *__restrict__ tw2_g,      \
         const PairItem *__restrict__ items, const int *__restrict__ part_begin, int n_parts, int n_buoys,     \
@@ -1130,6 +1146,12 @@ struct rmx_ctx {
     bool timing = false;
     int dbg = 0;
     bool resident = true;
+    int pk = 0;             // fused path: 1 = k_winp (k_win on packed fp32)
+    int win8 = 0;           // fused path: 1 = k_win8 (8 points x 1024 threads, 4 waves/SIMD), 0 = k_win
+    int stag = 1;           // k_win8: which waves run the two halves between barriers in the opposite order
+    float4* d_tw1_8 = nullptr;
+    float2* d_tb8 = nullptr;
+    float2* d_tc8 = nullptr;
     bool fused = true;      // one kernel per chunk: forward spectra + pairs in one workgroup per window   // pair kernel variant: 1 workgroup/CU with resident tables
     // device buffers
     float4* d_spec = nullptr;
@@ -1230,6 +1252,34 @@ static void build_tables(std::vector<float4>& tw1, std::vector<float2>& tw2) {
             const double ang = -two_pi * (double)((a * b) % 256) / 256.0;
             tw2[a * 16 + b] = make_float2((float)std::cos(ang), (float)std::sin(ang));
         }
+}
+
+// tables of k_win8 (win8.hpp; the same values tools/model_win8.py checks against numpy's FFT)
+static void build_tables8(std::vector<float4>& tw1, std::vector<float2>& tb, std::vector<float2>& tc) {
+    const double two_pi = 6.283185307179586476925286766559;
+    tw1.resize(4 * w8::kT8);
+    for (int T = 0; T < w8::kT8; ++T) {
+        const int p = T & 1, t1 = T >> 1;
+        float2 w[8];
+        for (int c0 = 0; c0 < 8; ++c0) {
+            double ang = -two_pi * (double)((t1 * c0) % kM) / (double)kM;      // W_M^(c0 t1)
+            if (p) ang += -two_pi * (double)t1 / (double)kL;                    // * W_L^t1 on odd lanes
+            w[c0] = make_float2((float)(std::cos(ang) * kTw1Scale), (float)(std::sin(ang) * kTw1Scale));
+        }
+        for (int j = 0; j < 4; ++j) tw1[j * w8::kT8 + T] = make_float4(w[2 * j].x, w[2 * j].y, w[2 * j + 1].x, w[2 * j + 1].y);
+    }
+    // rows in the order the first butterfly layer consumes them: w4, w1, w5, w2, w6, w3, w7 (w0 = 1 not stored)
+    const int order[7] = {4, 1, 5, 2, 6, 3, 7};
+    auto fill = [&](std::vector<float2>& t, int rows, int n) {
+        t.assign((size_t)rows * w8::kRowF2, make_float2(0.0f, 0.0f));
+        for (int r = 0; r < rows; ++r)
+            for (int k = 0; k < 7; ++k) {
+                const double ang = -two_pi * (double)((r * order[k]) % n) / (double)n;
+                t[(size_t)r * w8::kRowF2 + k] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+            }
+    };
+    fill(tb, 64, 512);   // W_512^(c1 * lane), lane = n0 + 8 n1
+    fill(tc, 8, 64);     // W_64^(d0 * n0)
 }
 
 static int ensure_events(rmx_ctx* c, size_t n) {
@@ -1518,6 +1568,8 @@ int rmx_create(rmx_ctx** out, int device_id, int n_buoys, int n_samples, int max
             int ncu = 0;
             if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && ncu > 0)
                 c->n_cus = ncu;
+            // experiment knob: fewer persistent workgroups than CUs (per-CU time without chip-wide contention)
+            if (const char* e = getenv("RMX_NCUS")) { const int v = atoi(e); if (v > 0 && v < c->n_cus) c->n_cus = v; }
         }
         RMX_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         c->own_stream = true;
@@ -1548,6 +1600,25 @@ int rmx_create(rmx_ctx** out, int device_id, int n_buoys, int n_samples, int max
         RMX_HIP(c, hipMemcpy(c->d_tw1, tw1.data(), tw1.size() * sizeof(float4), hipMemcpyHostToDevice));
         RMX_HIP(c, hipMemcpy(c->d_tw2, tw2.data(), tw2.size() * sizeof(float2), hipMemcpyHostToDevice));
         c->scratch_bytes = c->spec_bytes + tw1.size() * sizeof(float4) + tw2.size() * sizeof(float2);
+        {
+            std::vector<float4> t1;
+            std::vector<float2> tb, tc;
+            build_tables8(t1, tb, tc);
+            RMX_HIP(c, hipMalloc((void**)&c->d_tw1_8, t1.size() * sizeof(float4)));
+            RMX_HIP(c, hipMalloc((void**)&c->d_tb8, tb.size() * sizeof(float2)));
+            RMX_HIP(c, hipMalloc((void**)&c->d_tc8, tc.size() * sizeof(float2)));
+            RMX_HIP(c, hipMemcpy(c->d_tw1_8, t1.data(), t1.size() * sizeof(float4), hipMemcpyHostToDevice));
+            RMX_HIP(c, hipMemcpy(c->d_tb8, tb.data(), tb.size() * sizeof(float2), hipMemcpyHostToDevice));
+            RMX_HIP(c, hipMemcpy(c->d_tc8, tc.data(), tc.size() * sizeof(float2), hipMemcpyHostToDevice));
+            c->scratch_bytes += t1.size() * sizeof(float4) + (tb.size() + tc.size()) * sizeof(float2);
+            RMX_HIP(c, hipFuncSetAttribute((const void*)w8::k_win8<false>, hipFuncAttributeMaxDynamicSharedMemorySize, w8::kLdsWin8Bytes));
+            RMX_HIP(c, hipFuncSetAttribute((const void*)w8::k_win8<true>, hipFuncAttributeMaxDynamicSharedMemorySize, w8::kLdsWin8Bytes));
+            RMX_HIP(c, hipFuncSetAttribute((const void*)k_winp<false>, hipFuncAttributeMaxDynamicSharedMemorySize, pk::kLdsWinpBytes));
+            RMX_HIP(c, hipFuncSetAttribute((const void*)k_winp<true>, hipFuncAttributeMaxDynamicSharedMemorySize, pk::kLdsWinpBytes));
+            if (const char* e = getenv("RMX_PK")) c->pk = atoi(e);
+            if (const char* e = getenv("RMX_WIN8")) c->win8 = atoi(e);
+            if (const char* e = getenv("RMX_STAG")) c->stag = atoi(e);
+        }
         RMX_HIP(c, hipFuncSetAttribute((const void*)k_fwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
         RMX_HIP(c, hipFuncSetAttribute((const void*)k_fwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
         RMX_HIP(c, hipFuncSetAttribute((const void*)k_pair_res, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsResBytes));
@@ -1584,6 +1655,8 @@ void rmx_destroy(rmx_ctx* c) {
     if (c->d_spec) (void)hipFree(c->d_spec);
     if (c->d_tw1) (void)hipFree(c->d_tw1);
     if (c->d_tw2) (void)hipFree(c->d_tw2);
+    for (void* p : {(void*)c->d_tw1_8, (void*)c->d_tb8, (void*)c->d_tc8})
+        if (p) (void)hipFree(p);
     if (c->d_items) (void)hipFree(c->d_items);
     if (c->d_part_begin) (void)hipFree(c->d_part_begin);
     if (c->d_in) (void)hipFree(c->d_in);
@@ -1632,6 +1705,19 @@ int rmx_set_option(rmx_ctx* c, const char* key, long value) {
 #else
         return fail(c, RMX_E_UNSUPPORTED, "option 'dbg' exists only in the -DRMX_ABLATE timing build");
 #endif
+    }
+    if (!strcmp(key, "pk")) {
+        c->pk = value != 0;
+        return RMX_OK;
+    }
+    if (!strcmp(key, "win8")) {
+        c->win8 = value != 0;
+        return RMX_OK;
+    }
+    if (!strcmp(key, "stag")) {
+        if (value < 0 || value > 4) return fail(c, RMX_E_INVAL, "stag %ld not in 0..4", value);
+        c->stag = (int)value;
+        return RMX_OK;
     }
     if (!strcmp(key, "fused")) {
         c->fused = value != 0;
@@ -1780,7 +1866,23 @@ int rmx_xcorr_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pa
                 // one persistent workgroup per CU (the kernel's LDS footprint allows exactly one)
                 const int wgrid = sc < c->n_cus ? sc : c->n_cus;
                 if (c->timing) RMX_HIP(c, hipEventRecord(c->ev[c->ev_used], c->stream));
-                if (u8)
+                if (c->win8) {
+                    if (u8)
+                        hipLaunchKernelGGL(w8::k_win8<true>, dim3(wgrid), dim3(w8::kT8), w8::kLdsWin8Bytes, c->stream, d_iq,
+                                           c->d_spec, c->d_tw1_8, c->d_tb8, c->d_tc8, c->n_buoys, wfirst, out_scale, d_lag,
+                                           d_frac, d_peak, sc, c->stag);
+                    else
+                        hipLaunchKernelGGL(w8::k_win8<false>, dim3(wgrid), dim3(w8::kT8), w8::kLdsWin8Bytes, c->stream, d_iq,
+                                           c->d_spec, c->d_tw1_8, c->d_tb8, c->d_tc8, c->n_buoys, wfirst, out_scale, d_lag,
+                                           d_frac, d_peak, sc, c->stag);
+                } else if (c->pk) {
+                    if (u8)
+                        hipLaunchKernelGGL(k_winp<true>, dim3(wgrid), dim3(kThreads), pk::kLdsWinpBytes, c->stream, d_iq, c->d_spec,
+                                           c->d_tw1, c->d_tw2, c->n_buoys, wfirst, out_scale, d_lag, d_frac, d_peak, sc);
+                    else
+                        hipLaunchKernelGGL(k_winp<false>, dim3(wgrid), dim3(kThreads), pk::kLdsWinpBytes, c->stream, d_iq, c->d_spec,
+                                           c->d_tw1, c->d_tw2, c->n_buoys, wfirst, out_scale, d_lag, d_frac, d_peak, sc);
+                } else if (u8)
                     hipLaunchKernelGGL(k_win<true>, dim3(wgrid), dim3(kThreads), kLdsWinBytes, c->stream, d_iq, c->d_spec,
                                        c->d_tw1, c->d_tw2, c->n_buoys, wfirst, fwd_scale, out_scale, d_lag, d_frac,
                                        d_peak, sc, c->dbg);

@@ -23,7 +23,7 @@ def main():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = os.path.join(root, "profiles")
     os.makedirs(out, exist_ok=True)
-    ours = ("k_win", "k_fwd", "k_pair")
+    ours = ("k_win", "k_fwd", "k_pair", "g_cols", "g_rows", "g_final", "g_fwd_small", "g_pair_small", "k_caf")
     st = glob.glob(os.path.join(src, "stats", "*kernel_stats.csv"))
     if st:
         rows = list(csv.reader(open(st[0])))
