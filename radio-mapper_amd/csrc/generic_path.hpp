@@ -16,10 +16,12 @@
 //                                g_rows      DIF over n2 in place -> spectrum [k1'][k2'] (digit-reversed;
 //                                            the product is pointwise and the inverse undoes the order)
 //                      inverse : g_rows      X_j conj(X_i) formed on load, DIT over k2', * conj W_L^(n2 k1)
-//                                g_cols_inv  DIT over k1' -> r in natural order + the tile's partial
-//                                            argmax in 'full' order; g_final: reduce, 3 taps, parabola
-//                    HBM bytes per window: B*(8N + 3*16N) + P*(2*16N + 3*16N) = (56 B + 80 P) N, against
-//                    the 16 N P of the algorithmic model (cfg2: 408 N vs 48 N).
+//                                g_cols_inv  DIT over k1' -> r tile by tile in LDS only: the tile's partial
+//                                            argmax in 'full' order, its peak's taps, its two edge columns
+//                                            (halo); g_final: reduce, taps, parabola.  r never reaches HBM.
+//                    HBM bytes per window: B*(8N + 3*16N) + P*(2*16N + 2*16N) = (56 B + 64 P) N (+ 2-4 N P of
+//                    halo), against the 16 N P of the algorithmic model (cfg2: 360 N vs 48 N): the two-pass
+//                    minimum SURVEY.md section 8d quotes.
 // Twiddles: W_R^k tables per row length computed in double on the host; the large W_L^(a*b) factor of
 // the four-step is the product of two table entries (a*b mod L split into high and low digits).
 #pragma once
@@ -149,6 +151,27 @@ __device__ __forceinline__ void block_argmax(float& v, int& k, float* sv, int* s
     }
     v = sv[0];
     k = sk[0];
+    __syncthreads();
+}
+
+// the same with a wave-level shuffle reduction first: one (value, index) entry per wave in LDS (<= 16)
+__device__ __forceinline__ void block_argmax_w(float& v, int& k, float* sv, int* sk, int tid, int nthr) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float ov = __shfl_xor(v, off, 64);
+        const int ok = __shfl_xor(k, off, 64);
+        if (ov > v || (ov == v && ok < k)) { v = ov; k = ok; }
+    }
+    const int nw = (nthr + 63) >> 6;
+    if ((tid & 63) == 0) { sv[tid >> 6] = v; sk[tid >> 6] = k; }
+    __syncthreads();
+    v = sv[0];
+    k = sk[0];
+    for (int w = 1; w < nw; ++w) {
+        const float ov = sv[w];
+        const int ok = sk[w];
+        if (ov > v || (ov == v && ok < k)) { v = ov; k = ok; }
+    }
     __syncthreads();
 }
 
@@ -367,12 +390,18 @@ __global__ __launch_bounds__(1024) void g_cols_fwd(const void* __restrict__ iq, 
         o[(long)pos * L2 + c0 + c] = g_cmul(x[idx], w);
     }
 }
-// inverse: in[k1'][n2] (after the inverse row pass and its twiddle) -> r[n1][n2] natural order, plus this
-// tile's partial argmax of |r|^2 in 'full' order.  grid (L2/T, slots); parts = L2/T.
+// inverse: in[k1'][n2] (after the inverse row pass and its twiddle) -> this tile of r[n1][n2] in LDS only: the
+// tile's partial argmax of |r|^2 in 'full' order with the peak's two neighbour taps when they sit inside the
+// tile, and the |r|^2 of the tile's first and last column (the "halo" a neighbouring tile's peak may need).
+// r itself is never written to HBM (16 N bytes per pair-window saved).  grid (L2/T, slots); parts = L2/T.
+struct GTile {
+    float v;        // max |r|^2 of the tile
+    int k;          // its lowest 'full' index
+    float tm, tp;   // |r|^2 at k-1, k+1, or -1 where that lag lives in another tile (or does not exist)
+};
 template <int kColLogT>
-__global__ __launch_bounds__(1024) void g_cols_inv(const float2* __restrict__ in, float2* __restrict__ out,
-                                                   const float2* __restrict__ tw, int l1, int l2,
-                                                   float* __restrict__ pv, int* __restrict__ pk) {
+__global__ __launch_bounds__(1024) void g_cols_inv(const float2* __restrict__ in, const float2* __restrict__ tw, int l1,
+                                                   int l2, GTile* __restrict__ rec, float* __restrict__ halo) {
     constexpr int kColT = 1 << kColLogT;
     extern __shared__ __attribute__((aligned(16))) char gsm[];
     float2* x = reinterpret_cast<float2*>(gsm);
@@ -381,52 +410,85 @@ __global__ __launch_bounds__(1024) void g_cols_inv(const float2* __restrict__ in
     const int N = (int)(L >> 1);
     const int c0 = blockIdx.x * kColT;
     float2* twl = x + ((long)L1 << kColLogT) + (long)kColT * ((1 << (l1 >> 1)) + (L1 >> (l1 >> 1)));
+    float* sv = reinterpret_cast<float*>(x + ((long)L1 << kColLogT));   // 16 + 16 words in the (unused here) table region
+    int* sk = reinterpret_cast<int*>(sv + 16);
     for (int k = tid; k < (L1 >> 1); k += nthr) twl[k] = tw[k];
     const float2* src = in + (long)blockIdx.y * L;
     for (int idx = tid; idx < (L1 << kColLogT); idx += nthr)
         x[idx] = src[(long)(idx >> kColLogT) * L2 + c0 + (idx & (kColT - 1))];
     __syncthreads();
     lds_dit_inv<kColLogT>(x, l1, twl, tid, nthr);
-    float2* o = out + (long)blockIdx.y * L;
     float best = -1.0f;
     int bk = 0x7fffffff;
     for (int idx = tid; idx < (L1 << kColLogT); idx += nthr) {
         const long m = (long)(idx >> kColLogT) * L2 + c0 + (idx & (kColT - 1));
         const float2 e = x[idx];
-        o[m] = e;
         const int k = full_index((int)m, N);
         const float v = e.x * e.x + e.y * e.y;
         if (k >= 0 && (v > best || (v == best && k < bk))) { best = v; bk = k; }
     }
-    __syncthreads();                                            // x is reused as the reduction scratch
-    float* sv = reinterpret_cast<float*>(gsm);
-    int* sk = reinterpret_cast<int*>(sv + nthr);
-    block_argmax(best, bk, sv, sk, tid, nthr);
+    // halo: |r|^2 of columns c0 and c0 + T - 1, all rows: [slot][tile][2][L1]
+    float* hb = halo + ((long)blockIdx.y * gridDim.x + blockIdx.x) * 2L * L1;
+    for (int n1 = tid; n1 < 2 * L1; n1 += nthr) {
+        const int row = n1 & (L1 - 1), col = n1 < L1 ? 0 : kColT - 1;
+        const float2 e = x[(row << kColLogT) + col];
+        hb[n1] = e.x * e.x + e.y * e.y;
+    }
+    block_argmax_w(best, bk, sv, sk, tid, nthr);
     if (tid == 0) {
-        pv[(long)blockIdx.y * gridDim.x + blockIdx.x] = best;
-        pk[(long)blockIdx.y * gridDim.x + blockIdx.x] = bk;
+        GTile t;
+        t.v = best;
+        t.k = bk;
+        t.tm = t.tp = -1.0f;
+        if (bk > 0 && bk < 2 * N - 2) {
+            const long m = circ_index(bk, N);
+            const int c = (int)(m & (L2 - 1)) - c0, row = (int)(m >> l2);
+            // 'full' neighbours are the circular neighbours m -+ 1 (the excluded lag -N sits between the two
+            // ends of the 'full' range): inside this tile when the column is
+            if (c > 0) { const float2 e = x[(row << kColLogT) + c - 1]; t.tm = e.x * e.x + e.y * e.y; }
+            if (c < kColT - 1) { const float2 e = x[(row << kColLogT) + c + 1]; t.tp = e.x * e.x + e.y * e.y; }
+        }
+        rec[(long)blockIdx.y * gridDim.x + blockIdx.x] = t;
     }
 }
 
-// final reduction over a slot's partial maxima (one per column tile), 3 taps from r (natural order), parabola
-__global__ void g_final(const float2* __restrict__ r, int N, const float* __restrict__ pv,
-                        const int* __restrict__ pk, int parts, int n_slots, long out_base, float out_scale,
-                        int* __restrict__ lag_int, float* __restrict__ lag_frac, float* __restrict__ peak) {
-    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+// final reduction over a slot's tile records (one wave per slot), neighbour taps from the winning record or
+// from the halo columns of the adjacent tile, parabola
+__global__ __launch_bounds__(64) void g_final(int N, int l1, int l2, int col_log_t, const GTile* __restrict__ rec,
+                                              const float* __restrict__ halo, int parts, int n_slots, long out_base,
+                                              float out_scale, int* __restrict__ lag_int, float* __restrict__ lag_frac,
+                                              float* __restrict__ peak) {
+    const int slot = blockIdx.x, lane = threadIdx.x;
     if (slot >= n_slots) return;
     float best = -1.0f;
-    int bk = 0x7fffffff;
-    for (int p = 0; p < parts; ++p) {
-        const float v = pv[(long)slot * parts + p];
-        const int k = pk[(long)slot * parts + p];
-        if (v > best || (v == best && k < bk)) { best = v; bk = k; }
+    int bk = 0x7fffffff, bp = 0;
+    for (int p = lane; p < parts; p += 64) {
+        const GTile t = rec[(long)slot * parts + p];
+        if (t.v > best || (t.v == best && t.k < bk)) { best = t.v; bk = t.k; bp = p; }
     }
-    const float2* x = r + (long)slot * 2L * N;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float ov = __shfl_xor(best, off, 64);
+        const int ok = __shfl_xor(bk, off, 64), op = __shfl_xor(bp, off, 64);
+        if (ov > best || (ov == best && ok < bk)) { best = ov; bk = ok; bp = op; }
+    }
+    if (lane != 0) return;
+    const GTile t = rec[(long)slot * parts + bp];
+    const int L1 = 1 << l1, L2 = 1 << l2, T = 1 << col_log_t;
+    const long L = (long)L1 << l2;
     const float b = sqrtf(best) * out_scale;
     float frac = 0.0f;
     if (bk > 0 && bk < 2 * N - 2) {
-        const float2 ra = x[circ_index(bk - 1, N)], rc = x[circ_index(bk + 1, N)];
-        frac = parabola(sqrtf(ra.x * ra.x + ra.y * ra.y) * out_scale, b, sqrtf(rc.x * rc.x + rc.y * rc.y) * out_scale);
+        const long m = circ_index(bk, N);
+        auto tap = [&](float inside, long mm) -> float {
+            if (inside >= 0.0f) return inside;
+            mm &= (L - 1);                                   // circular neighbour, in another tile: an edge column
+            const int row = (int)(mm >> l2), col = (int)(mm & (L2 - 1));
+            const int tile = col >> col_log_t, cc = col & (T - 1);
+            return halo[(((long)slot * parts + tile) * 2 + (cc == 0 ? 0 : 1)) * L1 + row];
+        };
+        const float ra = tap(t.tm, m - 1 + L), rc = tap(t.tp, m + 1);
+        frac = parabola(sqrtf(ra) * out_scale, b, sqrtf(rc) * out_scale);
     }
     lag_int[out_base + slot] = bk - (N - 1);
     lag_frac[out_base + slot] = frac;

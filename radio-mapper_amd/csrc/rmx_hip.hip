@@ -574,7 +574,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
                                                      const float2* __restrict__ tw2_g, int n_buoys,
                                                      long first_window, float fwd_scale, float out_scale,
                                                      int* __restrict__ lag_int, float* __restrict__ lag_frac,
-                                                     float* __restrict__ peak, int n_win, int dbg_rt) {
+                                                     float* __restrict__ peak, int n_win, int dbg_rt, int stag) {
 #ifdef RMX_ABLATE
     const int dbg = dbg_rt;   // timing-only ablation build (wrong results): tools/ablate.sh, tools/ablate_run.py
 #else
@@ -919,7 +919,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
     // on the same stalls (all eight waves are otherwise barrier-aligned in lockstep).
     {
         const int M2 = (B - 1) * (B - 2) / 2;            // pairs of this phase
-        const bool late_h2 = (wave >> 1) & 1;   // SIMD pairs {a, a+2} vs {a+1, a+3}: measured best of the three splits
+        // SIMD pairs {a, a+2} vs {a+1, a+3} (stag 1): measured best of the splits; 0 = nobody, 5 = everybody late
+        const bool late_h2 = stag == 1 ? ((wave >> 1) & 1) : (stag == 5);
         auto j_of = [&](int i, int s) -> int { return (i & 1) ? (B - 1 - s) : (i + 1 + s); };
         int ci = 1, cs = 0;                              // pair m     (anchor, position in its run)
         int ni = 1, ns = 1;                              // pair m + 1
@@ -1166,9 +1167,9 @@ struct rmx_ctx {
     bool generic = false;
     int g_logL = 0, g_logL1 = 0, g_logL2 = 0, g_lo_bits = 0, g_chunk = 0;
     float2 *g_tw = nullptr, *g_tw1 = nullptr, *g_tw2 = nullptr, *g_thi = nullptr, *g_tlo = nullptr;
-    float2 *g_spec = nullptr, *g_tmp = nullptr, *g_prod = nullptr;
-    float* g_pv = nullptr;
-    int* g_pk = nullptr;
+    float2 *g_spec = nullptr, *g_prod = nullptr;
+    rmx::gen::GTile* g_rec = nullptr;   // per column tile: partial argmax + taps
+    float* g_halo = nullptr;            // per column tile: |r|^2 of its two edge columns
     rmx::gen::GPair* g_pairs = nullptr;
     long g_slots_alloc = 0;
     int g_pairs_n = -1;
@@ -1410,9 +1411,10 @@ static int generic_init(rmx_ctx* c) {
         RMX_HIP(c, hipFuncSetAttribute((const void*)(g_rows<true, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, rows_lds));
         RMX_HIP(c, hipFuncSetAttribute((const void*)(g_rows<false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, rows_lds));
     }
-    // windows per chunk: spectra (B*L) + products (P*L) + work buffer, 8 bytes each, under ~3 GiB
-    const long per_win = (long)(c->n_buoys + 2L * (all_pairs > c->n_buoys ? all_pairs : c->n_buoys)) * L * 8;
-    long chunk = (3L << 30) / per_win;
+    // windows per chunk: spectra (B*L) + products (P*L), 8 bytes each, under 32 GiB of the 288 (cfg2's 64
+    // windows of 2^20 samples are one chunk of 6.4 GB)
+    const long per_win = (long)(c->n_buoys + all_pairs) * L * 8;
+    long chunk = (32L << 30) / per_win;
     if (chunk < 1) chunk = 1;
     if (chunk > c->max_windows) chunk = c->max_windows;
     if (chunk > 4096) chunk = 4096;
@@ -1432,16 +1434,14 @@ static int generic_ensure(rmx_ctx* c, int n_pairs) {
         // (re)allocate the pair-dependent buffers when the pair count grows
         if (slots > c->g_slots_alloc) {
             if (c->g_prod) { (void)hipFree(c->g_prod); c->g_prod = nullptr; }
-            if (c->g_tmp) { (void)hipFree(c->g_tmp); c->g_tmp = nullptr; }
-            if (c->g_pv) { (void)hipFree(c->g_pv); c->g_pv = nullptr; }
-            if (c->g_pk) { (void)hipFree(c->g_pk); c->g_pk = nullptr; }
+            if (c->g_rec) { (void)hipFree(c->g_rec); c->g_rec = nullptr; }
+            if (c->g_halo) { (void)hipFree(c->g_halo); c->g_halo = nullptr; }
             c->g_slots_alloc = 0;
-            const long big = items > slots ? items : slots;
             RMX_HIP(c, hipMalloc((void**)&c->g_prod, slots * L * 8));
-            RMX_HIP(c, hipMalloc((void**)&c->g_tmp, big * L * 8));
-            const long parts = (1L << c->g_logL2) >> col_log_t(c->g_logL1);   // one partial argmax per column tile
-            RMX_HIP(c, hipMalloc((void**)&c->g_pv, slots * parts * sizeof(float)));
-            RMX_HIP(c, hipMalloc((void**)&c->g_pk, slots * parts * sizeof(int)));
+            const long parts = (1L << c->g_logL2) >> col_log_t(c->g_logL1);   // one record per column tile
+            RMX_HIP(c, hipMalloc((void**)&c->g_rec, slots * parts * sizeof(GTile)));
+            RMX_HIP(c, hipMalloc((void**)&c->g_halo, slots * parts * 2 * sizeof(float) << c->g_logL1));
+            c->scratch_bytes += slots * L * 8 + slots * parts * (sizeof(GTile) + (2 * sizeof(float) << c->g_logL1));
             c->g_slots_alloc = slots;
         }
     }
@@ -1506,13 +1506,13 @@ static int generic_batch(rmx_ctx* c, const void* d_iq, int n_windows, int n_pair
                            c->g_prod, c->g_tw2, l2, L1, l1, L, c->g_lo_bits, c->g_thi, c->g_tlo, 1.0f, (long)slots * L1,
                            c->g_spec, c->g_pairs, n_pairs, B);
         if (lt == 3)
-            hipLaunchKernelGGL((g_cols_inv<3>), dim3(ntiles, slots), dim3(cthr), clds, st, c->g_prod, c->g_tmp, c->g_tw1, l1, l2,
-                               c->g_pv, c->g_pk);
+            hipLaunchKernelGGL((g_cols_inv<3>), dim3(ntiles, slots), dim3(cthr), clds, st, c->g_prod, c->g_tw1, l1, l2, c->g_rec,
+                               c->g_halo);
         else
-            hipLaunchKernelGGL((g_cols_inv<4>), dim3(ntiles, slots), dim3(cthr), clds, st, c->g_prod, c->g_tmp, c->g_tw1, l1, l2,
-                               c->g_pv, c->g_pk);
-        hipLaunchKernelGGL(g_final, dim3((slots + 63) / 64), dim3(64), 0, st, c->g_tmp, N, c->g_pv, c->g_pk, ntiles,
-                           slots, (long)w0 * n_pairs, out_scale, d_lag, d_frac, d_peak);
+            hipLaunchKernelGGL((g_cols_inv<4>), dim3(ntiles, slots), dim3(cthr), clds, st, c->g_prod, c->g_tw1, l1, l2, c->g_rec,
+                               c->g_halo);
+        hipLaunchKernelGGL(g_final, dim3(slots), dim3(64), 0, st, N, l1, l2, lt, c->g_rec, c->g_halo, ntiles, slots,
+                           (long)w0 * n_pairs, out_scale, d_lag, d_frac, d_peak);
         RMX_HIP(c, hipGetLastError());
     }
     return RMX_OK;
@@ -1639,7 +1639,7 @@ void rmx_destroy(rmx_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     for (void* p : {(void*)c->g_tw, (void*)c->g_tw1, (void*)c->g_tw2, (void*)c->g_thi, (void*)c->g_tlo, (void*)c->g_spec,
-                    (void*)c->g_tmp, (void*)c->g_prod, (void*)c->g_pv, (void*)c->g_pk, (void*)c->g_pairs})
+                    (void*)c->g_prod, (void*)c->g_rec, (void*)c->g_halo, (void*)c->g_pairs})
         if (p) (void)hipFree(p);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     for (hipEvent_t e : c->copy_ev)
@@ -1715,7 +1715,7 @@ int rmx_set_option(rmx_ctx* c, const char* key, long value) {
         return RMX_OK;
     }
     if (!strcmp(key, "stag")) {
-        if (value < 0 || value > 4) return fail(c, RMX_E_INVAL, "stag %ld not in 0..4", value);
+        if (value < 0 || value > 5) return fail(c, RMX_E_INVAL, "stag %ld not in 0..5", value);
         c->stag = (int)value;
         return RMX_OK;
     }
@@ -1885,11 +1885,11 @@ int rmx_xcorr_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pa
                 } else if (u8)
                     hipLaunchKernelGGL(k_win<true>, dim3(wgrid), dim3(kThreads), kLdsWinBytes, c->stream, d_iq, c->d_spec,
                                        c->d_tw1, c->d_tw2, c->n_buoys, wfirst, fwd_scale, out_scale, d_lag, d_frac,
-                                       d_peak, sc, c->dbg);
+                                       d_peak, sc, c->dbg, c->stag);
                 else
                     hipLaunchKernelGGL(k_win<false>, dim3(wgrid), dim3(kThreads), kLdsWinBytes, c->stream, d_iq, c->d_spec,
                                        c->d_tw1, c->d_tw2, c->n_buoys, wfirst, fwd_scale, out_scale, d_lag, d_frac,
-                                       d_peak, sc, c->dbg);
+                                       d_peak, sc, c->dbg, c->stag);
                 RMX_HIP(c, hipGetLastError());
                 if (c->timing) {
                     RMX_HIP(c, hipEventRecord(c->ev[c->ev_used + 1], c->stream));

@@ -257,6 +257,7 @@ __global__ __launch_bounds__(kT8, 4) void k_win8(const void* __restrict__ iq_v, 
     else if (stag == 2) late_h2 = (wave >> 2) & 1;
     else if (stag == 3) late_h2 = (wave >> 3) & 1;
     else if (stag == 4) late_h2 = wave & 1;
+    else if (stag == 5) late_h2 = true;
     __syncthreads();
 
     for (int wl = blockIdx.x; wl < n_win; wl += gridDim.x) {

@@ -291,8 +291,9 @@ def test_caf_golden(xc, golden_dir, name):
         assert np.allclose(l0 + f0, l1 + f1, atol=TOL) and np.allclose(p0, p1, rtol=1e-5)
         # custom pair list
         sel = np.array([[1, 2], [0, 2]], np.int32)
+        at = [[tuple(p) for p in g["pairs"].tolist()].index(tuple(q)) for q in sel.tolist()]
         ds, ls, fs_, ps = eng.caf(iq, g["doppler_cps"], sel)
-        assert np.array_equal(ds, dop[:, [2, 1]]) and np.array_equal(ls, li[:, [2, 1]])
+        assert np.array_equal(ds, dop[:, at]) and np.array_equal(ls, li[:, at])
 
 
 @pytest.mark.parametrize("n_buoys,n_windows", [(2, 5), (3, 4), (5, 3), (7, 3), (16, 2), (32, 1)])
