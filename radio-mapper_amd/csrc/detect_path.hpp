@@ -38,16 +38,16 @@ __global__ __launch_bounds__(1024) void d_fft_db(const void* __restrict__ iq, fl
     for (int n = tid; n < N; n += nthr) {
         if constexpr (U8) {
             const uchar2 b = reinterpret_cast<const uchar2*>(iq)[w * N + n];
-            x[n] = make_float2((float)b.x - 127.5f, (float)b.y - 127.5f);
+            x[gen::lp(n)] = make_float2((float)b.x - 127.5f, (float)b.y - 127.5f);
         } else {
-            x[n] = reinterpret_cast<const float2*>(iq)[w * N + n];
+            x[gen::lp(n)] = reinterpret_cast<const float2*>(iq)[w * N + n];
         }
     }
     __syncthreads();
     lds_dif<0>(x, logN, tw, tid, nthr);
     float* o = pdb + w * N;
     for (int pos = tid; pos < N; pos += nthr) {
-        const float2 v = x[pos];
+        const float2 v = x[gen::lp(pos)];
         const float a = sqrtf(v.x * v.x + v.y * v.y);
         o[brev(pos, logN)] = 20.0f * log10f(a + 1e-12f);
     }

@@ -34,6 +34,9 @@ namespace rmx {
 namespace gen {
 
 constexpr int kGThreads = 256;
+// threads per row of the row kernels: two threads per radix-16 group (the passes leave half of them idle, the
+// streaming loops use all: measured better than one thread per group on the 2048-point rows of cfg2)
+__host__ __device__ constexpr int rows_tpr(int R) { return (R >> 3) < kGThreads ? ((R >> 3) > 0 ? (R >> 3) : 1) : kGThreads; }
 
 __device__ __forceinline__ float2 g_cmul(float2 a, float2 b) {
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
@@ -42,93 +45,147 @@ __device__ __forceinline__ float2 g_cmulc(float2 a, float2 b) {   // a * conj(b)
     return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
 }
 
-// In-place transforms of R = 2^logR points held in LDS; tw[k] = W_R^k, k < R/2.  Two radix-2 stages
-// are fused per pass (a radix-4 butterfly in registers: one LDS read and write and one barrier per
-// TWO stages; an odd logR leaves one plain radix-2 stage); the data flow, and with it the output
-// order, is that of the radix-2 network.  LOGT > 0: 2^LOGT interleaved transforms at once (element e
-// of transform c at x[(e << LOGT) | c]: a tile of columns of a row-major matrix; consecutive threads
-// take consecutive columns, so LDS accesses stay conflict free).
-// DIF: natural in -> bit-reversed out (forward, W = exp(-2 pi i / R)).
-template <int LOGT = 0>
-__device__ __forceinline__ void lds_dif(float2* x, int logR, const float2* __restrict__ tw, int tid, int nthr) {
-    constexpr int T = 1 << LOGT;
-    int s = logR - 1;
-    for (; s >= 1; s -= 2) {          // stages s (half = 2q) and s-1 (half = q)
-        const int q = 1 << (s - 1);
-        const int work = (1 << (logR - 2)) << LOGT;
-        for (int idx = tid; idx < work; idx += nthr) {
-            const int c = idx & (T - 1), i = idx >> LOGT;
-            const int l = i & (q - 1);
-            const int j = ((i >> (s - 1)) << (s + 1)) | l;
-            float2* p = x + ((long)j << LOGT) + c;
-            const int qs = q << LOGT;
-            const float2 x0 = p[0], x1 = p[qs], x2 = p[2 * qs], x3 = p[3 * qs];
-            const float2 wa = tw[l << (logR - 1 - s)];          // stage s, element j
-            const float2 wb = make_float2(wa.y, -wa.x);         // stage s, element j+q: wa * W_R^(R/4) = -i wa
-            const float2 w2 = tw[l << (logR - s)];              // stage s-1
-            const float2 a0 = make_float2(x0.x + x2.x, x0.y + x2.y);
-            const float2 a2 = g_cmul(make_float2(x0.x - x2.x, x0.y - x2.y), wa);
-            const float2 a1 = make_float2(x1.x + x3.x, x1.y + x3.y);
-            const float2 a3 = g_cmul(make_float2(x1.x - x3.x, x1.y - x3.y), wb);
-            p[0] = make_float2(a0.x + a1.x, a0.y + a1.y);
-            p[qs] = g_cmul(make_float2(a0.x - a1.x, a0.y - a1.y), w2);
-            p[2 * qs] = make_float2(a2.x + a3.x, a2.y + a3.y);
-            p[3 * qs] = g_cmul(make_float2(a2.x - a3.x, a2.y - a3.y), w2);
+// In-place transforms of R = 2^logR points held in LDS; tw[k] = W_R^k, k < R/2.  Up to FOUR radix-2 stages
+// are fused per pass: a radix-16 (8, 4, 2) butterfly in registers -- the blocks of fft_r16.hpp / win8.hpp -- so a
+// pass costs one LDS read and write of the data and one barrier per four stages (2048 points: 16 x 16 x 8, three
+// passes).  The data flow, and with it the output order, is that of the radix-2 network: a fused pass over
+// blocks of 2^b points with stride q = 2^(b-M) computes y[k] = DFT_{2^M}(x[j + m q])[k], multiplies by
+// W_{2^b}^(l k) (l = element index inside the sub-block) and stores it at j + bitrev_M(k) q.  LOGT > 0: 2^LOGT
+// interleaved transforms at once (element e of transform c at x[(e << LOGT) | c]: a tile of columns of a
+// row-major matrix; consecutive threads take consecutive columns, so LDS accesses stay conflict free).
+// Strided copy loop with U loads in flight per thread: all U global loads of a batch are issued before the
+// first value is consumed (a plain `for (n = tid; n < end; n += stride) dst[n] = src[n]` with run-time bounds
+// is compiled to one load, one wait and one store per trip: the kernels here are streaming kernels and
+// need the memory-level parallelism).
+template <int U, class LoadFn, class StoreFn>
+__device__ __forceinline__ void batched(int start, int end, int stride, LoadFn&& ld, StoreFn&& st) {
+    for (int n0 = start; n0 < end; n0 += U * stride) {
+        decltype(ld(0)) tmp[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int n = n0 + u * stride;
+            if (n < end) tmp[u] = ld(n);
         }
-        __syncthreads();
-    }
-    if (s == 0) {                     // odd logR: the last stage (half = 1, twiddle 1)
-        const int work = (1 << (logR - 1)) << LOGT;
-        for (int idx = tid; idx < work; idx += nthr) {
-            const int c = idx & (T - 1), i = idx >> LOGT;
-            float2* p = x + ((long)(2 * i) << LOGT) + c;
-            const float2 a = p[0], b = p[T];
-            p[0] = make_float2(a.x + b.x, a.y + b.y);
-            p[T] = make_float2(a.x - b.x, a.y - b.y);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int n = n0 + u * stride;
+            if (n < end) st(n, tmp[u]);
         }
-        __syncthreads();
     }
 }
-// DIT with conjugated twiddles: bit-reversed in -> natural out (inverse, unnormalised).
+
+// LDS element index -> padded position: one complex of padding per 16 keeps the stride-16 accesses of the last
+// fused passes (each thread walks 16 neighbouring elements) on distinct banks: lane i's element 16 i + m sits at
+// 17 i + m, and 17 is odd.  Every access to a transform buffer goes through lp().
+__host__ __device__ constexpr long lp(long e) { return e + (e >> 4); }
+template <int M>
+__device__ __forceinline__ constexpr int brev_m(int k) {
+    int r = 0;
+    for (int i = 0; i < M; ++i) r |= ((k >> i) & 1) << (M - 1 - i);
+    return r;
+}
+template <int RAD>
+__device__ __forceinline__ void dft_reg(float2 (&v)[RAD]) {   // natural order in and out
+    if constexpr (RAD == 16) dft16(v);
+    else if constexpr (RAD == 8) w8::dft8(v);
+    else if constexpr (RAD == 4) dft4(v[0], v[1], v[2], v[3]);
+    else {
+        const float2 a = v[0], b = v[1];
+        v[0] = make_float2(a.x + b.x, a.y + b.y);
+        v[1] = make_float2(a.x - b.x, a.y - b.y);
+    }
+}
+// W_R^e for any e < R from the half table
+__device__ __forceinline__ float2 tw_full(const float2* __restrict__ tw, int e, int half) {
+    const float2 w = tw[e & (half - 1)];
+    return (e & half) ? make_float2(-w.x, -w.y) : w;
+}
+// DIF pass: M stages on blocks of 2^b (forward, W = exp(-2 pi i / R))
+template <int M, int LOGT>
+__device__ __forceinline__ void dif_pass(float2* x, int logR, int b, const float2* __restrict__ tw, int tid, int nthr) {
+    constexpr int RAD = 1 << M, T = 1 << LOGT;
+    const int qb = b - M, q = 1 << qb, half = 1 << (logR - 1);
+    const int work = (1 << (logR - M)) << LOGT;
+    for (int idx = tid; idx < work; idx += nthr) {
+        const int c = idx & (T - 1), i = idx >> LOGT;
+        const int l = i & (q - 1);
+        const int j = ((i >> qb) << b) | l;
+        float2* p = x + lp(((long)j << LOGT) + c);
+        const int qs = q << LOGT;
+        // element m of the group: (m qs) further on, plus the padding crossed on the way (the group's first
+        // element has fewer than qs elements of its 16-block in front of it when qs < 16)
+        auto at = [&](int m) -> int { return m * qs + ((m * qs) >> 4); };
+        float2 v[RAD];
+#pragma unroll
+        for (int m = 0; m < RAD; ++m) v[m] = p[at(m)];
+        dft_reg<RAD>(v);
+        p[0] = v[0];
+        if (qb > 0) {
+            const int es = l << (logR - b);
+#pragma unroll
+            for (int k = 1; k < RAD; ++k) p[at(brev_m<M>(k))] = g_cmul(v[k], tw_full(tw, es * k, half));
+        } else {
+#pragma unroll
+            for (int k = 1; k < RAD; ++k) p[at(brev_m<M>(k))] = v[k];
+        }
+    }
+    __syncthreads();
+}
+// DIT pass with conjugated twiddles: the exact inverse data flow (unnormalised)
+template <int M, int LOGT>
+__device__ __forceinline__ void dit_pass(float2* x, int logR, int b, const float2* __restrict__ tw, int tid, int nthr) {
+    constexpr int RAD = 1 << M, T = 1 << LOGT;
+    const int qb = b - M, q = 1 << qb, half = 1 << (logR - 1);
+    const int work = (1 << (logR - M)) << LOGT;
+    for (int idx = tid; idx < work; idx += nthr) {
+        const int c = idx & (T - 1), i = idx >> LOGT;
+        const int l = i & (q - 1);
+        const int j = ((i >> qb) << b) | l;
+        float2* p = x + lp(((long)j << LOGT) + c);
+        const int qs = q << LOGT;
+        auto at = [&](int m) -> int { return m * qs + ((m * qs) >> 4); };
+        float2 v[RAD];      // (im, re)-swapped: swap o DFT o swap = conj(DFT)
+        {
+            const float2 e = p[0];
+            v[0] = make_float2(e.y, e.x);
+        }
+        if (qb > 0) {
+            const int es = l << (logR - b);
+#pragma unroll
+            for (int k = 1; k < RAD; ++k) {
+                const float2 e = g_cmulc(p[at(brev_m<M>(k))], tw_full(tw, es * k, half));
+                v[k] = make_float2(e.y, e.x);
+            }
+        } else {
+#pragma unroll
+            for (int k = 1; k < RAD; ++k) {
+                const float2 e = p[at(brev_m<M>(k))];
+                v[k] = make_float2(e.y, e.x);
+            }
+        }
+        dft_reg<RAD>(v);
+#pragma unroll
+        for (int m = 0; m < RAD; ++m) p[at(m)] = make_float2(v[m].y, v[m].x);
+    }
+    __syncthreads();
+}
+// DIF: natural in -> bit-reversed out (forward).  Passes: radix 16 while four stages remain, then the rest.
+template <int LOGT = 0>
+__device__ __forceinline__ void lds_dif(float2* x, int logR, const float2* __restrict__ tw, int tid, int nthr) {
+    int b = logR;
+    for (; b >= 4; b -= 4) dif_pass<4, LOGT>(x, logR, b, tw, tid, nthr);
+    if (b == 3) dif_pass<3, LOGT>(x, logR, b, tw, tid, nthr);
+    else if (b == 2) dif_pass<2, LOGT>(x, logR, b, tw, tid, nthr);
+    else if (b == 1) dif_pass<1, LOGT>(x, logR, b, tw, tid, nthr);
+}
+// DIT with conjugated twiddles: bit-reversed in -> natural out (inverse, unnormalised): the same passes backwards
 template <int LOGT = 0>
 __device__ __forceinline__ void lds_dit_inv(float2* x, int logR, const float2* __restrict__ tw, int tid, int nthr) {
-    constexpr int T = 1 << LOGT;
-    int s = 0;
-    if (logR & 1) {                   // odd logR: the first stage (half = 1, twiddle 1) on its own
-        const int work = (1 << (logR - 1)) << LOGT;
-        for (int idx = tid; idx < work; idx += nthr) {
-            const int c = idx & (T - 1), i = idx >> LOGT;
-            float2* p = x + ((long)(2 * i) << LOGT) + c;
-            const float2 a = p[0], b = p[T];
-            p[0] = make_float2(a.x + b.x, a.y + b.y);
-            p[T] = make_float2(a.x - b.x, a.y - b.y);
-        }
-        __syncthreads();
-        s = 1;
-    }
-    for (; s + 1 < logR; s += 2) {    // stages s (half = q) and s+1 (half = 2q)
-        const int q = 1 << s;
-        const int work = (1 << (logR - 2)) << LOGT;
-        for (int idx = tid; idx < work; idx += nthr) {
-            const int c = idx & (T - 1), i = idx >> LOGT;
-            const int l = i & (q - 1);
-            const int j = ((i >> s) << (s + 2)) | l;
-            float2* p = x + ((long)j << LOGT) + c;
-            const int qs = q << LOGT;
-            const float2 w1 = tw[l << (logR - 1 - s)];          // stage s
-            const float2 wa = tw[l << (logR - 2 - s)];          // stage s+1, element j
-            const float2 wb = make_float2(wa.y, -wa.x);         // stage s+1, element j+q: -i wa (conjugated below)
-            const float2 x0 = p[0], x1 = g_cmulc(p[qs], w1), x2 = p[2 * qs], x3 = g_cmulc(p[3 * qs], w1);
-            const float2 a0 = make_float2(x0.x + x1.x, x0.y + x1.y), a1 = make_float2(x0.x - x1.x, x0.y - x1.y);
-            const float2 b0 = g_cmulc(make_float2(x2.x + x3.x, x2.y + x3.y), wa);
-            const float2 b1 = g_cmulc(make_float2(x2.x - x3.x, x2.y - x3.y), wb);
-            p[0] = make_float2(a0.x + b0.x, a0.y + b0.y);
-            p[2 * qs] = make_float2(a0.x - b0.x, a0.y - b0.y);
-            p[qs] = make_float2(a1.x + b1.x, a1.y + b1.y);
-            p[3 * qs] = make_float2(a1.x - b1.x, a1.y - b1.y);
-        }
-        __syncthreads();
-    }
+    const int r = logR & 3;
+    if (r == 3) dit_pass<3, LOGT>(x, logR, r, tw, tid, nthr);
+    else if (r == 2) dit_pass<2, LOGT>(x, logR, r, tw, tid, nthr);
+    else if (r == 1) dit_pass<1, LOGT>(x, logR, r, tw, tid, nthr);
+    for (int b = r + 4; b <= logR; b += 4) dit_pass<4, LOGT>(x, logR, b, tw, tid, nthr);
 }
 
 // 'full' order index (lag ascending from -(N-1)) of circular index m of an L = 2N point correlation;
@@ -190,22 +247,24 @@ __global__ __launch_bounds__(1024) void g_fwd_small(const void* __restrict__ iq,
     float2* x = reinterpret_cast<float2*>(gsm);
     const int L = 1 << logL, tid = threadIdx.x, nthr = blockDim.x;
     const long item = first_item + blockIdx.x;
-    for (int n = tid; n < L; n += nthr) {
-        float2 v = make_float2(0.f, 0.f);
-        if (n < N) {
-            if constexpr (U8) {
-                const uchar2 b = reinterpret_cast<const uchar2*>(iq)[item * N + n];
-                v = make_float2((float)b.x - 127.5f, (float)b.y - 127.5f);
-            } else {
-                v = reinterpret_cast<const float2*>(iq)[item * N + n];
-            }
-        }
-        x[n] = v;
-    }
+    for (int n = N + tid; n < L; n += nthr) x[lp(n)] = make_float2(0.f, 0.f);   // the zero-padded half
+    batched<8>(tid, N, nthr,
+               [&](int n) -> float2 {
+                   if constexpr (U8) {
+                       const uchar2 b = reinterpret_cast<const uchar2*>(iq)[item * N + n];
+                       return make_float2((float)b.x - 127.5f, (float)b.y - 127.5f);
+                   } else {
+                       return reinterpret_cast<const float2*>(iq)[item * N + n];
+                   }
+               },
+               [&](int n, float2 v) { x[lp(n)] = v; });
     __syncthreads();
     lds_dif(x, logL, tw, tid, nthr);
     float2* out = spec + (long)blockIdx.x * L;
-    for (int n = tid; n < L; n += nthr) out[n] = make_float2(x[n].x * scale, x[n].y * scale);
+    for (int n = tid; n < L; n += nthr) {
+        const float2 e = x[lp(n)];
+        out[n] = make_float2(e.x * scale, e.y * scale);
+    }
 }
 
 struct GPair {
@@ -221,13 +280,14 @@ __global__ __launch_bounds__(1024) void g_pair_small(const float2* __restrict__ 
     extern __shared__ __attribute__((aligned(16))) char gsm[];
     float2* x = reinterpret_cast<float2*>(gsm);
     const int L = 1 << logL, tid = threadIdx.x, nthr = blockDim.x;
-    float* sv = reinterpret_cast<float*>(gsm + (size_t)L * 8);
+    float* sv = reinterpret_cast<float*>(gsm + (size_t)lp(L) * 8);
     int* sk = reinterpret_cast<int*>(sv + nthr);
     const int wl = blockIdx.x / n_pairs, q = blockIdx.x % n_pairs;
     const GPair pr = pairs[q];
     const float2* xi = spec + ((long)wl * n_buoys + pr.i) * L;
     const float2* xj = spec + ((long)wl * n_buoys + pr.j) * L;
-    for (int n = tid; n < L; n += nthr) x[n] = g_cmulc(xj[n], xi[n]);   // X_j conj(X_i)
+    batched<4>(tid, L, nthr, [&](int n) -> float4 { const float2 a = xj[n], b = xi[n]; return make_float4(a.x, a.y, b.x, b.y); },
+               [&](int n, float4 v) { x[lp(n)] = g_cmulc(make_float2(v.x, v.y), make_float2(v.z, v.w)); });   // X_j conj(X_i)
     __syncthreads();
     lds_dit_inv(x, logL, tw, tid, nthr);
     float best = -1.0f;
@@ -235,7 +295,8 @@ __global__ __launch_bounds__(1024) void g_pair_small(const float2* __restrict__ 
     for (int m = tid; m < L; m += nthr) {
         const int k = full_index(m, N);
         if (k < 0) continue;
-        const float v = x[m].x * x[m].x + x[m].y * x[m].y;
+        const float2 e = x[lp(m)];
+        const float v = e.x * e.x + e.y * e.y;
         if (v > best || (v == best && k < bk)) { best = v; bk = k; }
     }
     block_argmax(best, bk, sv, sk, tid, nthr);
@@ -243,7 +304,7 @@ __global__ __launch_bounds__(1024) void g_pair_small(const float2* __restrict__ 
         const float b = sqrtf(best) * out_scale;
         float frac = 0.0f;
         if (bk > 0 && bk < 2 * N - 2) {
-            const float2 ra = x[circ_index(bk - 1, N)], rc = x[circ_index(bk + 1, N)];
+            const float2 ra = x[lp(circ_index(bk - 1, N))], rc = x[lp(circ_index(bk + 1, N))];
             frac = parabola(sqrtf(ra.x * ra.x + ra.y * ra.y) * out_scale, b,
                             sqrtf(rc.x * rc.x + rc.y * rc.y) * out_scale);
         }
@@ -277,18 +338,18 @@ __global__ __launch_bounds__(kGThreads) void g_rows(float2* __restrict__ data, c
                                                     const float2* __restrict__ tlo, float scale, long total_rows,
                                                     const float2* __restrict__ spec = nullptr,
                                                     const GPair* __restrict__ pairs = nullptr, int n_pairs = 0,
-                                                    int n_buoys = 0) {
+                                                    int n_buoys = 0, int tpr_arg = 0) {
     extern __shared__ __attribute__((aligned(16))) char gsm[];
     const int R = 1 << logR;
-    const int tpr = (R >> 2) < kGThreads ? ((R >> 2) > 0 ? (R >> 2) : 1) : kGThreads;   // threads per row
+    const int tpr = tpr_arg > 0 ? tpr_arg : rows_tpr(R);                               // threads per row
     const int rpw = kGThreads / tpr;                                                   // rows per workgroup
     const int g = threadIdx.x / tpr, tid = threadIdx.x % tpr;
     const long ridx = (long)blockIdx.x * rpw + g;
     const bool live = ridx < total_rows;
-    float2* x = reinterpret_cast<float2*>(gsm) + (long)g * R;
+    float2* x = reinterpret_cast<float2*>(gsm) + (long)g * lp(R);
     // the row's twiddle table goes to LDS once (butterflies would otherwise fetch two entries per
     // radix-4 group through the vector memory path, a dependent cache-latency access in the inner loop)
-    float2* twl = reinterpret_cast<float2*>(gsm) + (long)rpw * R + (TW ? (long)rpw * ((1 << (logR >> 1)) + (R >> (logR >> 1))) : 0);
+    float2* twl = reinterpret_cast<float2*>(gsm) + (long)rpw * lp(R) + (TW ? (long)rpw * ((1 << (logR >> 1)) + (R >> (logR >> 1))) : 0);
     for (int k = threadIdx.x; k < (R >> 1); k += kGThreads) twl[k] = tw[k];
     float2* row = data + ridx * R;
     const int rib = (int)(ridx & (n_rows - 1));   // row index inside its batch element (n_rows = 2^row_bits)
@@ -299,9 +360,10 @@ __global__ __launch_bounds__(kGThreads) void g_rows(float2* __restrict__ data, c
             const GPair pr = pairs[q];
             const float2* xi = spec + (((long)wl * n_buoys + pr.i) * n_rows + rib) * R;
             const float2* xj = spec + (((long)wl * n_buoys + pr.j) * n_rows + rib) * R;
-            for (int n = tid; n < R; n += tpr) x[n] = g_cmulc(xj[n], xi[n]);
+            batched<4>(tid, R, tpr, [&](int n) -> float4 { const float2 a = xj[n], b = xi[n]; return make_float4(a.x, a.y, b.x, b.y); },
+                       [&](int n, float4 v) { x[lp(n)] = g_cmulc(make_float2(v.x, v.y), make_float2(v.z, v.w)); });
         } else {
-            for (int n = tid; n < R; n += tpr) x[n] = row[n];
+            batched<8>(tid, R, tpr, [&](int n) -> float2 { return row[n]; }, [&](int n, float2 v) { x[lp(n)] = v; });
         }
     }
     __syncthreads();
@@ -311,7 +373,7 @@ __global__ __launch_bounds__(kGThreads) void g_rows(float2* __restrict__ data, c
         // per-row LDS tables T1[e & (2^a - 1)] * T2[e >> a] (2^a + R/2^a big-table lookups per row
         // instead of two uncoalesced gathers per element)
         const int a = logR >> 1, n1 = 1 << a, n2 = R >> a;
-        float2* t1 = reinterpret_cast<float2*>(gsm) + (long)(kGThreads / tpr) * R + (long)g * (n1 + n2);
+        float2* t1 = reinterpret_cast<float2*>(gsm) + (long)(kGThreads / tpr) * lp(R) + (long)g * (n1 + n2);
         float2* t2 = t1 + n1;
         const long c = FWD ? (long)rib : (long)brev(rib, row_bits);
         for (int e = tid; e < n1 + n2; e += tpr) {
@@ -323,12 +385,15 @@ __global__ __launch_bounds__(kGThreads) void g_rows(float2* __restrict__ data, c
         for (int n = tid; n < R; n += tpr) {
             const int e = FWD ? brev(n, logR) : n;
             const float2 w = g_cmul(t1[e & (n1 - 1)], t2[e >> a]);
-            const float2 v = FWD ? g_cmul(x[n], w) : g_cmulc(x[n], w);
+            const float2 v = FWD ? g_cmul(x[lp(n)], w) : g_cmulc(x[lp(n)], w);
             row[n] = make_float2(v.x * scale, v.y * scale);
         }
     } else {
         if (!live) return;
-        for (int n = tid; n < R; n += tpr) row[n] = make_float2(x[n].x * scale, x[n].y * scale);
+        for (int n = tid; n < R; n += tpr) {
+            const float2 e = x[lp(n)];
+            row[n] = make_float2(e.x * scale, e.y * scale);
+        }
     }
 }
 
@@ -354,27 +419,26 @@ __global__ __launch_bounds__(1024) void g_cols_fwd(const void* __restrict__ iq, 
     const long L = (long)L1 << l2, N = L >> 1;
     const int c0 = blockIdx.x * kColT;
     const long item = first_item + blockIdx.y;
-    float2* twl = x + ((long)L1 << kColLogT) + (long)kColT * ((1 << (l1 >> 1)) + (L1 >> (l1 >> 1)));   // behind x and the tables
+    float2* twl = x + lp((long)L1 << kColLogT) + (long)kColT * ((1 << (l1 >> 1)) + (L1 >> (l1 >> 1)));   // behind x and the tables
     for (int k = tid; k < (L1 >> 1); k += nthr) twl[k] = tw[k];
-    for (int idx = tid; idx < (L1 << kColLogT); idx += nthr) {
-        const int c = idx & (kColT - 1), n1 = idx >> kColLogT;
-        float2 v = make_float2(0.f, 0.f);
-        if (n1 < (L1 >> 1)) {
-            const long n = (long)n1 * L2 + c0 + c;
-            if constexpr (U8) {
-                const uchar2 b = reinterpret_cast<const uchar2*>(iq)[item * N + n];
-                v = make_float2((float)b.x - 127.5f, (float)b.y - 127.5f);
-            } else {
-                v = reinterpret_cast<const float2*>(iq)[item * N + n];
-            }
-        }
-        x[idx] = v;
-    }
+    const int nz = (L1 >> 1) << kColLogT;                     // only the rows n1 < L1/2 are non-zero
+    for (int idx = nz + tid; idx < (L1 << kColLogT); idx += nthr) x[lp(idx)] = make_float2(0.f, 0.f);
+    batched<8>(tid, nz, nthr,
+               [&](int idx) -> float2 {
+                   const long n = (long)(idx >> kColLogT) * L2 + c0 + (idx & (kColT - 1));
+                   if constexpr (U8) {
+                       const uchar2 b = reinterpret_cast<const uchar2*>(iq)[item * N + n];
+                       return make_float2((float)b.x - 127.5f, (float)b.y - 127.5f);
+                   } else {
+                       return reinterpret_cast<const float2*>(iq)[item * N + n];
+                   }
+               },
+               [&](int idx, float2 v) { x[lp(idx)] = v; });
     __syncthreads();
     lds_dif<kColLogT>(x, l1, twl, tid, nthr);
     // per-column twiddle tables: W_L^(n2*e) = T1[e & (2^a-1)] * T2[e >> a]   (n2*e < L: no reduction)
     const int a = l1 >> 1, na = 1 << a, nb = L1 >> a;
-    float2* tab = x + ((long)L1 << kColLogT);               // [16][na + nb]
+    float2* tab = x + lp((long)L1 << kColLogT);             // [16][na + nb]
     for (int idx = tid; idx < kColT * (na + nb); idx += nthr) {
         const int c = idx / (na + nb), e = idx % (na + nb);
         const long ee = e < na ? (long)e : ((long)(e - na) << a);
@@ -387,7 +451,7 @@ __global__ __launch_bounds__(1024) void g_cols_fwd(const void* __restrict__ iq, 
         const int k1 = brev(pos, l1);
         const float2* tc = tab + c * (na + nb);
         const float2 w = g_cmul(tc[k1 & (na - 1)], tc[na + (k1 >> a)]);
-        o[(long)pos * L2 + c0 + c] = g_cmul(x[idx], w);
+        o[(long)pos * L2 + c0 + c] = g_cmul(x[lp(idx)], w);
     }
 }
 // inverse: in[k1'][n2] (after the inverse row pass and its twiddle) -> this tile of r[n1][n2] in LDS only: the
@@ -409,20 +473,21 @@ __global__ __launch_bounds__(1024) void g_cols_inv(const float2* __restrict__ in
     const long L = (long)L1 << l2;
     const int N = (int)(L >> 1);
     const int c0 = blockIdx.x * kColT;
-    float2* twl = x + ((long)L1 << kColLogT) + (long)kColT * ((1 << (l1 >> 1)) + (L1 >> (l1 >> 1)));
-    float* sv = reinterpret_cast<float*>(x + ((long)L1 << kColLogT));   // 16 + 16 words in the (unused here) table region
+    float2* twl = x + lp((long)L1 << kColLogT) + (long)kColT * ((1 << (l1 >> 1)) + (L1 >> (l1 >> 1)));
+    float* sv = reinterpret_cast<float*>(x + lp((long)L1 << kColLogT));   // 16 + 16 words in the (unused here) table region
     int* sk = reinterpret_cast<int*>(sv + 16);
     for (int k = tid; k < (L1 >> 1); k += nthr) twl[k] = tw[k];
     const float2* src = in + (long)blockIdx.y * L;
-    for (int idx = tid; idx < (L1 << kColLogT); idx += nthr)
-        x[idx] = src[(long)(idx >> kColLogT) * L2 + c0 + (idx & (kColT - 1))];
+    batched<8>(tid, L1 << kColLogT, nthr,
+               [&](int idx) -> float2 { return src[(long)(idx >> kColLogT) * L2 + c0 + (idx & (kColT - 1))]; },
+               [&](int idx, float2 v) { x[lp(idx)] = v; });
     __syncthreads();
     lds_dit_inv<kColLogT>(x, l1, twl, tid, nthr);
     float best = -1.0f;
     int bk = 0x7fffffff;
     for (int idx = tid; idx < (L1 << kColLogT); idx += nthr) {
         const long m = (long)(idx >> kColLogT) * L2 + c0 + (idx & (kColT - 1));
-        const float2 e = x[idx];
+        const float2 e = x[lp(idx)];
         const int k = full_index((int)m, N);
         const float v = e.x * e.x + e.y * e.y;
         if (k >= 0 && (v > best || (v == best && k < bk))) { best = v; bk = k; }
@@ -431,7 +496,7 @@ __global__ __launch_bounds__(1024) void g_cols_inv(const float2* __restrict__ in
     float* hb = halo + ((long)blockIdx.y * gridDim.x + blockIdx.x) * 2L * L1;
     for (int n1 = tid; n1 < 2 * L1; n1 += nthr) {
         const int row = n1 & (L1 - 1), col = n1 < L1 ? 0 : kColT - 1;
-        const float2 e = x[(row << kColLogT) + col];
+        const float2 e = x[lp((row << kColLogT) + col)];
         hb[n1] = e.x * e.x + e.y * e.y;
     }
     block_argmax_w(best, bk, sv, sk, tid, nthr);
@@ -445,8 +510,8 @@ __global__ __launch_bounds__(1024) void g_cols_inv(const float2* __restrict__ in
             const int c = (int)(m & (L2 - 1)) - c0, row = (int)(m >> l2);
             // 'full' neighbours are the circular neighbours m -+ 1 (the excluded lag -N sits between the two
             // ends of the 'full' range): inside this tile when the column is
-            if (c > 0) { const float2 e = x[(row << kColLogT) + c - 1]; t.tm = e.x * e.x + e.y * e.y; }
-            if (c < kColT - 1) { const float2 e = x[(row << kColLogT) + c + 1]; t.tp = e.x * e.x + e.y * e.y; }
+            if (c > 0) { const float2 e = x[lp((row << kColLogT) + c - 1)]; t.tm = e.x * e.x + e.y * e.y; }
+            if (c < kColT - 1) { const float2 e = x[lp((row << kColLogT) + c + 1)]; t.tp = e.x * e.x + e.y * e.y; }
         }
         rec[(long)blockIdx.y * gridDim.x + blockIdx.x] = t;
     }

@@ -1349,21 +1349,27 @@ static int upload(rmx_ctx* c, float2** dst, const std::vector<float2>& v) {
 
 // windows up to this zero-padded length run with the whole transform in LDS (128 KiB of the 160)
 static constexpr long kGenSmallMaxL = 16384;
-static int gen_small_threads(long L) { return L >= 8192 ? 1024 : 256; }
+static int gen_small_threads(long L) { const long t = L >> 4; return t >= 1024 ? 1024 : (t < 64 ? 64 : (int)t); }   // one radix-16 group per thread and pass
 // dynamic LDS of the four-step kernels
+static int gen_rows_tpr(int R) {
+    int t = gen::rows_tpr(R);
+    if (const char* e = getenv("RMX_ROWS_TPR")) { const int v = atoi(e); if (v >= 1 && v <= gen::kGThreads && (v & (v - 1)) == 0 && v <= R) t = v; }
+    return t;
+}
 static size_t gen_rows_lds(int R) {                     // rows + per-row twiddle tables (TW passes)
-    const int tpr = (R >> 2) < gen::kGThreads ? ((R >> 2) > 0 ? (R >> 2) : 1) : gen::kGThreads;
+    const int tpr = gen_rows_tpr(R);
     int logR = 0;
     while ((1 << logR) < R) ++logR;
     const int a = logR >> 1;
-    return ((size_t)(gen::kGThreads / tpr) * ((size_t)R + (1 << a) + (R >> a)) + (size_t)(R >> 1)) * 8;   // + W_R table
+    return ((size_t)(gen::kGThreads / tpr) * ((size_t)gen::lp(R) + (1 << a) + (R >> a)) + (size_t)(R >> 1)) * 8;   // + W_R table
 }
 static size_t gen_cols_lds(int l1) {                    // [L1][T] tile + T per-column twiddle tables
     const int a = l1 >> 1, T = 1 << gen::col_log_t(l1);
-    return ((size_t)(1 << l1) * T + (size_t)T * ((1 << a) + ((1 << l1) >> a)) + (size_t)((1 << l1) >> 1)) * 8;   // + W_L1 table
+    return ((size_t)gen::lp((long)(1 << l1) * T) + (size_t)T * ((1 << a) + ((1 << l1) >> a)) + (size_t)((1 << l1) >> 1)) * 8;   // + W_L1 table
 }
-static int gen_cols_threads(int l1) {                   // one radix-4 work item per thread and pass, <= 1024
-    const long work = (((long)1 << l1) << gen::col_log_t(l1)) / 4;
+static int gen_cols_threads(int l1) {                   // one radix-16 work item per thread and pass, <= 1024
+    const long work = (((long)1 << l1) << gen::col_log_t(l1)) / 16;
+    if (const char* e = getenv("RMX_COLS_THREADS")) { const int v = atoi(e); if (v >= 64 && v <= 1024) return v; }
     return work >= 1024 ? 1024 : (work < 64 ? 64 : (int)work);
 }
 
@@ -1380,7 +1386,7 @@ static int generic_init(rmx_ctx* c) {
         make_row_table(t, (int)L);
         int rc = upload(c, &c->g_tw, t);
         if (rc) return rc;
-        const int slds = (int)(L * 8 + gen_small_threads(L) * 8);
+        const int slds = (int)(gen::lp(L) * 8 + 1024 * 8);
         RMX_HIP(c, hipFuncSetAttribute((const void*)g_pair_small, hipFuncAttributeMaxDynamicSharedMemorySize, slds));
         RMX_HIP(c, hipFuncSetAttribute((const void*)g_fwd_small<false>, hipFuncAttributeMaxDynamicSharedMemorySize, slds));
         RMX_HIP(c, hipFuncSetAttribute((const void*)g_fwd_small<true>, hipFuncAttributeMaxDynamicSharedMemorySize, slds));
@@ -1473,19 +1479,19 @@ static int generic_batch(rmx_ctx* c, const void* d_iq, int n_windows, int n_pair
         if (L <= kGenSmallMaxL) {
             const int sthr = gen_small_threads(L);
             if (u8)
-                hipLaunchKernelGGL(g_fwd_small<true>, dim3(items), dim3(sthr), (size_t)L * 8, st, d_iq, c->g_spec,
+                hipLaunchKernelGGL(g_fwd_small<true>, dim3(items), dim3(sthr), (size_t)gen::lp(L) * 8, st, d_iq, c->g_spec,
                                    c->g_tw, N, logL, first_item, fwd_scale);
             else
-                hipLaunchKernelGGL(g_fwd_small<false>, dim3(items), dim3(sthr), (size_t)L * 8, st, d_iq, c->g_spec,
+                hipLaunchKernelGGL(g_fwd_small<false>, dim3(items), dim3(sthr), (size_t)gen::lp(L) * 8, st, d_iq, c->g_spec,
                                    c->g_tw, N, logL, first_item, fwd_scale);
-            hipLaunchKernelGGL(g_pair_small, dim3(slots), dim3(sthr), (size_t)L * 8 + (size_t)sthr * 8, st, c->g_spec,
+            hipLaunchKernelGGL(g_pair_small, dim3(slots), dim3(sthr), (size_t)gen::lp(L) * 8 + (size_t)sthr * 8, st, c->g_spec,
                                c->g_tw, c->g_pairs, n_pairs, B, N, logL, (long)w0, out_scale, d_lag, d_frac, d_peak);
             RMX_HIP(c, hipGetLastError());
             continue;
         }
         const int l1 = c->g_logL1, l2 = c->g_logL2, L1 = 1 << l1, L2 = 1 << l2;
         auto rows_grid = [](long rows, int R) -> dim3 {      // workgroups for `rows` rows of length R
-            const int tpr = (R >> 2) < kGThreads ? ((R >> 2) > 0 ? (R >> 2) : 1) : kGThreads;
+            const int tpr = gen_rows_tpr(R);
             const int rpw = kGThreads / tpr;
             return dim3((unsigned)((rows + rpw - 1) / rpw));
         };
@@ -1500,11 +1506,12 @@ static int generic_batch(rmx_ctx* c, const void* d_iq, int n_windows, int n_pair
         else    { if (lt == 3) RMX_COLS_FWD(false, 3); else RMX_COLS_FWD(false, 4); }
 #undef RMX_COLS_FWD
         hipLaunchKernelGGL((g_rows<true, false, false>), rows_grid((long)items * L1, L2), dim3(kGThreads), rlds, st, c->g_spec,
-                           c->g_tw2, l2, L1, l1, L, c->g_lo_bits, c->g_thi, c->g_tlo, fwd_scale, (long)items * L1);
+                           c->g_tw2, l2, L1, l1, L, c->g_lo_bits, c->g_thi, c->g_tlo, fwd_scale, (long)items * L1,
+                           (const float2*)nullptr, (const GPair*)nullptr, 0, 0, gen_rows_tpr(L2));
         // pairs: row pass ([product on load] rows(L2)^-1 * conj W_L^(n2 k1)), column pass (-> r natural + partial argmax)
         hipLaunchKernelGGL((g_rows<false, true, true>), rows_grid((long)slots * L1, L2), dim3(kGThreads), rlds, st,
                            c->g_prod, c->g_tw2, l2, L1, l1, L, c->g_lo_bits, c->g_thi, c->g_tlo, 1.0f, (long)slots * L1,
-                           c->g_spec, c->g_pairs, n_pairs, B);
+                           c->g_spec, c->g_pairs, n_pairs, B, gen_rows_tpr(L2));
         if (lt == 3)
             hipLaunchKernelGGL((g_cols_inv<3>), dim3(ntiles, slots), dim3(cthr), clds, st, c->g_prod, c->g_tw1, l1, l2, c->g_rec,
                                c->g_halo);
@@ -2168,8 +2175,8 @@ int rmx_detect_batch(rmx_ctx* c, const void* iq, int n_windows, int n_samples, f
         RMX_HIP(c, hipMalloc((void**)&c->dt_tw, t.size() * sizeof(float2)));
         RMX_HIP(c, hipMemcpy(c->dt_tw, t.data(), t.size() * sizeof(float2), hipMemcpyHostToDevice));
         c->dt_logn = logn;
-        RMX_HIP(c, hipFuncSetAttribute((const void*)rmx::det::d_fft_db<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8));
-        RMX_HIP(c, hipFuncSetAttribute((const void*)rmx::det::d_fft_db<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8));
+        RMX_HIP(c, hipFuncSetAttribute((const void*)rmx::det::d_fft_db<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rmx::gen::lp(16384) * 8));
+        RMX_HIP(c, hipFuncSetAttribute((const void*)rmx::det::d_fft_db<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rmx::gen::lp(16384) * 8));
         RMX_HIP(c, hipFuncSetAttribute((const void*)rmx::det::d_peaks, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        16384 * 6 + 8192));
     }
@@ -2205,10 +2212,10 @@ int rmx_detect_batch(rmx_ctx* c, const void* iq, int n_windows, int n_samples, f
     }
     const int fthr = N >= 4096 ? 1024 : (N >= 1024 ? 256 : 64);
     if (u8)
-        hipLaunchKernelGGL(rmx::det::d_fft_db<true>, dim3(n_windows), dim3(fthr), (size_t)N * 8, c->stream, d_iq, c->dt_pdb,
+        hipLaunchKernelGGL(rmx::det::d_fft_db<true>, dim3(n_windows), dim3(fthr), (size_t)rmx::gen::lp(N) * 8, c->stream, d_iq, c->dt_pdb,
                            c->dt_tw, logn);
     else
-        hipLaunchKernelGGL(rmx::det::d_fft_db<false>, dim3(n_windows), dim3(fthr), (size_t)N * 8, c->stream, d_iq, c->dt_pdb,
+        hipLaunchKernelGGL(rmx::det::d_fft_db<false>, dim3(n_windows), dim3(fthr), (size_t)rmx::gen::lp(N) * 8, c->stream, d_iq, c->dt_pdb,
                            c->dt_tw, logn);
     RMX_HIP(c, hipGetLastError());
     const int pthr = N >= 4096 ? 1024 : 256;
