@@ -53,6 +53,15 @@ __device__ __forceinline__ float2 g_cmulc(float2 a, float2 b) {   // a * conj(b)
 // W_{2^b}^(l k) (l = element index inside the sub-block) and stores it at j + bitrev_M(k) q.  LOGT > 0: 2^LOGT
 // interleaved transforms at once (element e of transform c at x[(e << LOGT) | c]: a tile of columns of a
 // row-major matrix; consecutive threads take consecutive columns, so LDS accesses stay conflict free).
+// De-rotation of a window sample by a Doppler phasor (rmx_caf_batch): separately rounded products and sums, as
+// numpy multiplies complex64 arrays (no contraction), so that the rotated window equals the oracle's bit for bit.
+__device__ __forceinline__ float2 rot_mul(float2 v, float2 r) {
+#pragma clang fp contract(off)
+    const float re = v.x * r.x - v.y * r.y;
+    const float im = v.x * r.y + v.y * r.x;
+    return make_float2(re, im);
+}
+
 // Strided copy loop with U loads in flight per thread: all U global loads of a batch are issued before the
 // first value is consumed (a plain `for (n = tid; n < end; n += stride) dst[n] = src[n]` with run-time bounds
 // is compiled to one load, one wait and one store per trip: the kernels here are streaming kernels and
@@ -242,7 +251,8 @@ __device__ __forceinline__ float parabola(float a, float b, float c) {
 template <bool U8>
 __global__ __launch_bounds__(1024) void g_fwd_small(const void* __restrict__ iq, float2* __restrict__ spec,
                                                          const float2* __restrict__ tw, int N, int logL,
-                                                         long first_item, float scale) {
+                                                         long first_item, float scale,
+                                                         const float2* __restrict__ rot = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char gsm[];
     float2* x = reinterpret_cast<float2*>(gsm);
     const int L = 1 << logL, tid = threadIdx.x, nthr = blockDim.x;
@@ -257,7 +267,7 @@ __global__ __launch_bounds__(1024) void g_fwd_small(const void* __restrict__ iq,
                        return reinterpret_cast<const float2*>(iq)[item * N + n];
                    }
                },
-               [&](int n, float2 v) { x[lp(n)] = v; });
+               [&](int n, float2 v) { x[lp(n)] = rot ? rot_mul(v, rot[n]) : v; });
     __syncthreads();
     lds_dif(x, logL, tw, tid, nthr);
     float2* out = spec + (long)blockIdx.x * L;
@@ -271,7 +281,7 @@ struct GPair {
     int i, j;
 };
 
-__global__ __launch_bounds__(1024) void g_pair_small(const float2* __restrict__ spec,
+__global__ __launch_bounds__(1024) void g_pair_small(const float2* __restrict__ spec, const float2* __restrict__ spec_j,
                                                           const float2* __restrict__ tw,
                                                           const GPair* __restrict__ pairs, int n_pairs,
                                                           int n_buoys, int N, int logL, long first_window,
@@ -285,7 +295,7 @@ __global__ __launch_bounds__(1024) void g_pair_small(const float2* __restrict__ 
     const int wl = blockIdx.x / n_pairs, q = blockIdx.x % n_pairs;
     const GPair pr = pairs[q];
     const float2* xi = spec + ((long)wl * n_buoys + pr.i) * L;
-    const float2* xj = spec + ((long)wl * n_buoys + pr.j) * L;
+    const float2* xj = spec_j + ((long)wl * n_buoys + pr.j) * L;
     batched<4>(tid, L, nthr, [&](int n) -> float4 { const float2 a = xj[n], b = xi[n]; return make_float4(a.x, a.y, b.x, b.y); },
                [&](int n, float4 v) { x[lp(n)] = g_cmulc(make_float2(v.x, v.y), make_float2(v.z, v.w)); });   // X_j conj(X_i)
     __syncthreads();
@@ -337,6 +347,7 @@ __global__ __launch_bounds__(kGThreads) void g_rows(float2* __restrict__ data, c
                                                     const float2* __restrict__ thi,
                                                     const float2* __restrict__ tlo, float scale, long total_rows,
                                                     const float2* __restrict__ spec = nullptr,
+                                                    const float2* __restrict__ spec_j = nullptr,
                                                     const GPair* __restrict__ pairs = nullptr, int n_pairs = 0,
                                                     int n_buoys = 0, int tpr_arg = 0) {
     extern __shared__ __attribute__((aligned(16))) char gsm[];
@@ -359,7 +370,7 @@ __global__ __launch_bounds__(kGThreads) void g_rows(float2* __restrict__ data, c
             const int wl = (int)(slot / n_pairs), q = (int)(slot % n_pairs);
             const GPair pr = pairs[q];
             const float2* xi = spec + (((long)wl * n_buoys + pr.i) * n_rows + rib) * R;
-            const float2* xj = spec + (((long)wl * n_buoys + pr.j) * n_rows + rib) * R;
+            const float2* xj = spec_j + (((long)wl * n_buoys + pr.j) * n_rows + rib) * R;
             batched<4>(tid, R, tpr, [&](int n) -> float4 { const float2 a = xj[n], b = xi[n]; return make_float4(a.x, a.y, b.x, b.y); },
                        [&](int n, float4 v) { x[lp(n)] = g_cmulc(make_float2(v.x, v.y), make_float2(v.z, v.w)); });
         } else {
@@ -411,7 +422,8 @@ template <bool U8, int kColLogT>
 __global__ __launch_bounds__(1024) void g_cols_fwd(const void* __restrict__ iq, float2* __restrict__ out,
                                                    const float2* __restrict__ tw, int l1, int l2, long first_item,
                                                    int lo_bits, const float2* __restrict__ thi,
-                                                   const float2* __restrict__ tlo) {
+                                                   const float2* __restrict__ tlo,
+                                                   const float2* __restrict__ rot = nullptr) {
     constexpr int kColT = 1 << kColLogT;
     extern __shared__ __attribute__((aligned(16))) char gsm[];
     float2* x = reinterpret_cast<float2*>(gsm);
@@ -433,7 +445,9 @@ __global__ __launch_bounds__(1024) void g_cols_fwd(const void* __restrict__ iq, 
                        return reinterpret_cast<const float2*>(iq)[item * N + n];
                    }
                },
-               [&](int idx, float2 v) { x[lp(idx)] = v; });
+               [&](int idx, float2 v) {
+                   x[lp(idx)] = rot ? rot_mul(v, rot[(long)(idx >> kColLogT) * L2 + c0 + (idx & (kColT - 1))]) : v;
+               });
     __syncthreads();
     lds_dif<kColLogT>(x, l1, twl, tid, nthr);
     // per-column twiddle tables: W_L^(n2*e) = T1[e & (2^a-1)] * T2[e >> a]   (n2*e < L: no reduction)

@@ -80,7 +80,7 @@ template <bool U8>
 __global__ __launch_bounds__(kThreads, 4) void k_fwd(const void* __restrict__ iq_v, float4* __restrict__ spec,
                                                      const float4* __restrict__ tw1_g,
                                                      const float2* __restrict__ tw2_g, long first_item,
-                                                     float scale) {
+                                                     float scale, const float2* __restrict__ rot) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2* xl = reinterpret_cast<float2*>(smem);
     float2* tw2_lds = reinterpret_cast<float2*>(smem + kLdsXchg);
@@ -104,6 +104,10 @@ __global__ __launch_bounds__(kThreads, 4) void k_fwd(const void* __restrict__ iq
         const float2* x = reinterpret_cast<const float2*>(iq_v) + item * kM;
 #pragma unroll
         for (int q = 0; q < 16; ++q) v[q] = x[q * 256 + u];
+    }
+    if (rot) {   // rmx_caf_batch: the window de-rotated by this Doppler hypothesis (rounded as numpy rounds it)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = gen::rot_mul(v[q], rot[q * 256 + u]);
     }
     // odd sub-transform: x[n] * W_L^n = x * W32^q * W_L^u ; W_L^u is folded into tw1 (odd lanes)
     if (p) {
@@ -133,7 +137,8 @@ __global__ __launch_bounds__(kThreads, 4) void k_fwd(const void* __restrict__ iq
 //   out arrays are indexed [(first_window + wl) * n_pairs + item.out].
 // Streaming variant (k_pair_str, option "resident" = 0): two workgroups per CU (<= 128 VGPRs); TW1,
 // X_i and X_j are re-read every pair.  The resident variant is k_pair_res below.
-__device__ __forceinline__ void pair_body(const float4* __restrict__ spec, const float4* __restrict__ tw1_g,
+__device__ __forceinline__ void pair_body(const float4* __restrict__ spec, const float4* __restrict__ spec_j,
+                                          const float4* __restrict__ tw1_g,
                                           const float2* __restrict__ tw2_g, const PairItem* __restrict__ items,
                                           const int* __restrict__ part_begin, int n_parts, int n_buoys,
                                           int n_pairs, int xcd_map, long first_window, float out_scale,
@@ -177,7 +182,7 @@ __device__ __forceinline__ void pair_body(const float4* __restrict__ spec, const
     PairItem pi = items[it_begin < it_end ? it_begin : 0];
     if (it_begin < it_end) {
         const float4* xi = spec + (wbase + pi.i) * (8 * kThreads);
-        const float4* xj = spec + (wbase + pi.j) * (8 * kThreads);
+        const float4* xj = spec_j + (wbase + pi.j) * (8 * kThreads);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             sa[j] = xi[j * kThreads + t];
@@ -231,7 +236,7 @@ __device__ __forceinline__ void pair_body(const float4* __restrict__ spec, const
             if (it + 1 < it_end) {
                 pi = items[it + 1];
                 const float4* xi = spec + (wbase + pi.i) * (8 * kThreads);
-                const float4* xj = spec + (wbase + pi.j) * (8 * kThreads);
+                const float4* xj = spec_j + (wbase + pi.j) * (8 * kThreads);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     sa[j] = xi[j * kThreads + t];
@@ -344,7 +349,7 @@ __device__ __forceinline__ void resolve_pair(const float* magbuf, const float2* 
 }
 
 __global__ __launch_bounds__(kThreads, 2) void k_pair_res(
-    const float4* __restrict__ spec, const float4* __restrict__ tw1_g, const float2* __restrict__ tw2_g,
+    const float4* __restrict__ spec, const float4* __restrict__ spec_j, const float4* __restrict__ tw1_g, const float2* __restrict__ tw2_g,
     const PairItem* __restrict__ items, const int* __restrict__ part_begin, int n_parts, int n_buoys, int n_pairs,
     int xcd_map, long first_window, float out_scale, int* __restrict__ lag_int, float* __restrict__ lag_frac,
     float* __restrict__ peak, int dbg_rt) {
@@ -392,7 +397,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_pair_res(
     int cur_i = pi.i;
     {
         const float4* xi = spec + (wbase + pi.i) * (8 * kThreads);
-        const float4* xj = spec + (wbase + pi.j) * (8 * kThreads);
+        const float4* xj = spec_j + (wbase + pi.j) * (8 * kThreads);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             sa[j] = xi[j * kThreads + t];
@@ -413,7 +418,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_pair_res(
         }
         if (it + 1 < it_end && !(dbg & 16)) {   // request the next pair's spectra: a whole pair of compute hides it
             pi = items[it + 1];
-            const float4* xj = spec + (wbase + pi.j) * (8 * kThreads);
+            const float4* xj = spec_j + (wbase + pi.j) * (8 * kThreads);
 #pragma unroll
             for (int j = 0; j < 8; ++j) sb[j] = xj[j * kThreads + t];
             if (pi.i != cur_i) {
@@ -977,49 +982,24 @@ __global__ __launch_bounds__(kThreads, 2) void k_winp(const void* __restrict__ i
 }
 
 #define RMX_PAIR_ARGS                                                                                         \
-    const float4 *__restrict__ spec, const float4 *__restrict__ tw1_g, const float2 *__restrict__ tw2_g,      \
+    const float4 *__restrict__ spec, const float4 *__restrict__ spec_j, const float4 *__restrict__ tw1_g,     \
+        const float2 *__restrict__ tw2_g,                                                                     \
         const PairItem *__restrict__ items, const int *__restrict__ part_begin, int n_parts, int n_buoys,     \
         int n_pairs, int xcd_map, long first_window, float out_scale, int *__restrict__ lag_int,              \
         float *__restrict__ lag_frac, float *__restrict__ peak
 #define RMX_PAIR_PASS                                                                                         \
-    spec, tw1_g, tw2_g, items, part_begin, n_parts, n_buoys, n_pairs, xcd_map, first_window, out_scale,      \
+    spec, spec_j, tw1_g, tw2_g, items, part_begin, n_parts, n_buoys, n_pairs, xcd_map, first_window, out_scale,      \
         lag_int, lag_frac, peak
 
 __global__ __launch_bounds__(kThreads, 4) void k_pair_str(RMX_PAIR_ARGS) { pair_body(RMX_PAIR_PASS); }
 
 
-// ---- CAF helpers --------------------------------------------------------------------------------
-// aug[w][b] = x[w][b], aug[w][B + b] = x[w][b] * rot[n]   (rot = exp(-2 pi i nu_d n) as complex64)
-template <bool U8>
-__global__ void k_caf_augment(const void* __restrict__ iq, const float2* __restrict__ rot, float2* __restrict__ aug,
-                              int n_buoys, int n_samples, long n_items) {
-#pragma clang fp contract(off)   // products and sums rounded one by one (and identically for both input types)
-    for (long item = blockIdx.y; item < n_items; item += gridDim.y) {      // item = w * B + b (grid.y <= 65535)
-    const long w = item / n_buoys, b = item % n_buoys;
-    float2* o0 = aug + ((w * 2 * n_buoys) + b) * n_samples;
-    float2* o1 = aug + ((w * 2 * n_buoys) + n_buoys + b) * n_samples;
-    for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < n_samples; n += gridDim.x * blockDim.x) {
-        float2 v;
-        if constexpr (U8) {
-            const uchar2 q = reinterpret_cast<const uchar2*>(iq)[item * n_samples + n];
-            v = make_float2((float)q.x - 127.5f, (float)q.y - 127.5f);
-        } else {
-            v = reinterpret_cast<const float2*>(iq)[item * n_samples + n];
-        }
-        const float2 r = rot[n];
-        o0[n] = v;
-        // separately rounded products, as numpy multiplies complex64 (no contraction)
-        const float re = v.x * r.x - v.y * r.y;
-        const float im = v.x * r.y + v.y * r.x;
-        o1[n] = make_float2(re, im);
-    }
-    }
-}
-__global__ void k_caf_select(int d, int n, const int* __restrict__ lag_d, const float* __restrict__ frac_d,
+// ---- CAF helper: running best hypothesis per pair-window -------------------------------------------
+__global__ void k_caf_select(int d, long first, long n, const int* __restrict__ lag_d, const float* __restrict__ frac_d,
                              const float* __restrict__ peak_d, int* __restrict__ dop, int* __restrict__ lag,
                              float* __restrict__ frac, float* __restrict__ peak) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    const long i = first + (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= first + n) return;
     if (d == 0 || peak_d[i] > peak[i]) {   // strict: ties keep the lowest d
         dop[i] = d; lag[i] = lag_d[i]; frac[i] = frac_d[i]; peak[i] = peak_d[i];
     }
@@ -1167,7 +1147,7 @@ struct rmx_ctx {
     bool generic = false;
     int g_logL = 0, g_logL1 = 0, g_logL2 = 0, g_lo_bits = 0, g_chunk = 0;
     float2 *g_tw = nullptr, *g_tw1 = nullptr, *g_tw2 = nullptr, *g_thi = nullptr, *g_tlo = nullptr;
-    float2 *g_spec = nullptr, *g_prod = nullptr;
+    float2 *g_spec = nullptr, *g_spec_r = nullptr, *g_prod = nullptr;   // spectra, de-rotated spectra (CAF), products
     rmx::gen::GTile* g_rec = nullptr;   // per column tile: partial argmax + taps
     float* g_halo = nullptr;            // per column tile: |r|^2 of its two edge columns
     rmx::gen::GPair* g_pairs = nullptr;
@@ -1183,9 +1163,8 @@ struct rmx_ctx {
     // rmx_solve_batch work buffers
     double* sv_buoys = nullptr;  int* sv_pairs = nullptr;  size_t sv_pairs_cap = 0;
     void* sv_in = nullptr;  size_t sv_in_bytes = 0;  void* sv_out = nullptr;  size_t sv_out_bytes = 0;
-    // CAF (rmx_caf_batch): child engine over the 2B-buoy augmented windows + work buffers
-    rmx_ctx* caf_child = nullptr;
-    float2* caf_aug = nullptr;  size_t caf_aug_bytes = 0;
+    // CAF (rmx_caf_batch): de-rotated spectra of the N = 4096 path, phasor table, per-hypothesis results
+    float4* d_spec_r = nullptr;  size_t spec_r_bytes = 0;
     float2* caf_rot = nullptr;  size_t caf_rot_elems = 0;
     int* caf_lag = nullptr;  float* caf_frac = nullptr;  float* caf_peak = nullptr;  int* caf_dop = nullptr;
     size_t caf_out_elems = 0;
@@ -1393,6 +1372,7 @@ static int generic_init(rmx_ctx* c) {
     } else {
         // columns of length L1 <= 1024 (a tile of 16 columns is L1*128 bytes of LDS), rows of L2 = L/L1 <= 8192
         c->g_logL1 = c->g_logL / 2 < 10 ? c->g_logL / 2 : 10;
+        if (const char* e = getenv("RMX_LOGL1")) { const int v = atoi(e); if (v >= 4 && v <= 10 && c->g_logL - v <= 13 && c->g_logL - v >= 4) c->g_logL1 = v; }
         c->g_logL2 = c->g_logL - c->g_logL1;
         c->g_lo_bits = (c->g_logL + 1) / 2;
         make_row_table(t, 1 << c->g_logL1);
@@ -1462,65 +1442,103 @@ static int generic_ensure(rmx_ctx* c, int n_pairs) {
     return RMX_OK;
 }
 
-static int generic_batch(rmx_ctx* c, const void* d_iq, int n_windows, int n_pairs, int* d_lag, float* d_frac,
-                         float* d_peak, bool u8) {
+// forward spectra of windows [w0, w0 + wc) of d_iq into g_spec (rot == nullptr) or, de-rotated by the phasor
+// table rot[N], into g_spec_r (rmx_caf_batch)
+static int generic_forward(rmx_ctx* c, const void* d_iq, int w0, int wc, bool u8, const float2* rot) {
     using namespace gen;
-    int rc = generic_ensure(c, n_pairs);
-    if (rc) return rc;
+    const int N = c->n_samples, logL = c->g_logL, B = c->n_buoys;
+    const long L = 1L << logL;
+    const float fwd_scale = std::ldexp(1.0f, -(logL / 2));
+    hipStream_t st = c->stream;
+    const int items = wc * B;
+    const long first_item = (long)w0 * B;
+    if (rot && !c->g_spec_r) {
+        RMX_HIP(c, hipMalloc((void**)&c->g_spec_r, (size_t)c->g_chunk * B * L * 8));
+        c->scratch_bytes += (size_t)c->g_chunk * B * L * 8;
+    }
+    float2* dst = rot ? c->g_spec_r : c->g_spec;
+    if (L <= kGenSmallMaxL) {
+        const int sthr = gen_small_threads(L);
+        if (u8)
+            hipLaunchKernelGGL(g_fwd_small<true>, dim3(items), dim3(sthr), (size_t)gen::lp(L) * 8, st, d_iq, dst, c->g_tw, N, logL,
+                               first_item, fwd_scale, rot);
+        else
+            hipLaunchKernelGGL(g_fwd_small<false>, dim3(items), dim3(sthr), (size_t)gen::lp(L) * 8, st, d_iq, dst, c->g_tw, N, logL,
+                               first_item, fwd_scale, rot);
+        RMX_HIP(c, hipGetLastError());
+        return RMX_OK;
+    }
+    const int l1 = c->g_logL1, l2 = c->g_logL2, L1 = 1 << l1, L2 = 1 << l2;
+    const int cthr = gen_cols_threads(l1), tpr = gen_rows_tpr(L2);
+    const size_t clds = gen_cols_lds(l1), rlds = gen_rows_lds(L2);
+    const int lt = col_log_t(l1), ntiles = L2 >> lt;
+    // column pass (zero-padded window -> [k1'][n2] * W_L^(n2 k1)), row pass in place (-> [k1'][k2'])
+#define RMX_COLS_FWD(U8V, LT)                                                                                          \
+    hipLaunchKernelGGL((g_cols_fwd<U8V, LT>), dim3(ntiles, items), dim3(cthr), clds, st, d_iq, dst, c->g_tw1, l1, l2,  \
+                       first_item, c->g_lo_bits, c->g_thi, c->g_tlo, rot)
+    if (u8) { if (lt == 3) RMX_COLS_FWD(true, 3); else RMX_COLS_FWD(true, 4); }
+    else    { if (lt == 3) RMX_COLS_FWD(false, 3); else RMX_COLS_FWD(false, 4); }
+#undef RMX_COLS_FWD
+    const long rows = (long)items * L1;
+    const int rpw = kGThreads / tpr;
+    hipLaunchKernelGGL((g_rows<true, false, false>), dim3((unsigned)((rows + rpw - 1) / rpw)), dim3(kGThreads), rlds, st, dst,
+                       c->g_tw2, l2, L1, l1, L, c->g_lo_bits, c->g_thi, c->g_tlo, fwd_scale, rows, (const float2*)nullptr,
+                       (const float2*)nullptr, (const GPair*)nullptr, 0, 0, tpr);
+    RMX_HIP(c, hipGetLastError());
+    return RMX_OK;
+}
+
+// pair kernels of that chunk: X_i from g_spec, X_j from g_spec (use_rot false) or g_spec_r; results at
+// [(w0 + wl) * n_pairs + q] of the three output arrays
+static int generic_pairs(rmx_ctx* c, int w0, int wc, int n_pairs, int* d_lag, float* d_frac, float* d_peak,
+                         bool use_rot) {
+    using namespace gen;
     const int N = c->n_samples, logL = c->g_logL, B = c->n_buoys;
     const long L = 1L << logL;
     const int hs = logL / 2;
-    const float fwd_scale = std::ldexp(1.0f, -hs), out_scale = std::ldexp(1.0f, -(logL - 2 * hs));
+    const float out_scale = std::ldexp(1.0f, -(logL - 2 * hs));
     hipStream_t st = c->stream;
+    const int slots = wc * n_pairs;
+    const float2* spec_j = use_rot ? c->g_spec_r : c->g_spec;
+    if (L <= kGenSmallMaxL) {
+        const int sthr = gen_small_threads(L);
+        hipLaunchKernelGGL(g_pair_small, dim3(slots), dim3(sthr), (size_t)gen::lp(L) * 8 + (size_t)sthr * 8, st, c->g_spec,
+                           spec_j, c->g_tw, c->g_pairs, n_pairs, B, N, logL, (long)w0, out_scale, d_lag, d_frac, d_peak);
+        RMX_HIP(c, hipGetLastError());
+        return RMX_OK;
+    }
+    const int l1 = c->g_logL1, l2 = c->g_logL2, L1 = 1 << l1, L2 = 1 << l2;
+    const int cthr = gen_cols_threads(l1), tpr = gen_rows_tpr(L2);
+    const size_t clds = gen_cols_lds(l1), rlds = gen_rows_lds(L2);
+    const int lt = col_log_t(l1), ntiles = L2 >> lt;
+    const long rows = (long)slots * L1;
+    const int rpw = kGThreads / tpr;
+    // row pass ([product on load] rows(L2)^-1 * conj W_L^(n2 k1)), column pass (-> tile records + halo), reduction
+    hipLaunchKernelGGL((g_rows<false, true, true>), dim3((unsigned)((rows + rpw - 1) / rpw)), dim3(kGThreads), rlds, st, c->g_prod,
+                       c->g_tw2, l2, L1, l1, L, c->g_lo_bits, c->g_thi, c->g_tlo, 1.0f, rows, (const float2*)c->g_spec, spec_j,
+                       c->g_pairs, n_pairs, B, tpr);
+    if (lt == 3)
+        hipLaunchKernelGGL((g_cols_inv<3>), dim3(ntiles, slots), dim3(cthr), clds, st, c->g_prod, c->g_tw1, l1, l2, c->g_rec,
+                           c->g_halo);
+    else
+        hipLaunchKernelGGL((g_cols_inv<4>), dim3(ntiles, slots), dim3(cthr), clds, st, c->g_prod, c->g_tw1, l1, l2, c->g_rec,
+                           c->g_halo);
+    hipLaunchKernelGGL(g_final, dim3(slots), dim3(64), 0, st, N, l1, l2, lt, c->g_rec, c->g_halo, ntiles, slots,
+                       (long)w0 * n_pairs, out_scale, d_lag, d_frac, d_peak);
+    RMX_HIP(c, hipGetLastError());
+    return RMX_OK;
+}
+
+static int generic_batch(rmx_ctx* c, const void* d_iq, int n_windows, int n_pairs, int* d_lag, float* d_frac,
+                         float* d_peak, bool u8) {
+    int rc = generic_ensure(c, n_pairs);
+    if (rc) return rc;
     for (int w0 = 0; w0 < n_windows; w0 += c->g_chunk) {
         const int wc = n_windows - w0 < c->g_chunk ? n_windows - w0 : c->g_chunk;
-        const int items = wc * B, slots = wc * n_pairs;
-        const long first_item = (long)w0 * B;
-        if (L <= kGenSmallMaxL) {
-            const int sthr = gen_small_threads(L);
-            if (u8)
-                hipLaunchKernelGGL(g_fwd_small<true>, dim3(items), dim3(sthr), (size_t)gen::lp(L) * 8, st, d_iq, c->g_spec,
-                                   c->g_tw, N, logL, first_item, fwd_scale);
-            else
-                hipLaunchKernelGGL(g_fwd_small<false>, dim3(items), dim3(sthr), (size_t)gen::lp(L) * 8, st, d_iq, c->g_spec,
-                                   c->g_tw, N, logL, first_item, fwd_scale);
-            hipLaunchKernelGGL(g_pair_small, dim3(slots), dim3(sthr), (size_t)gen::lp(L) * 8 + (size_t)sthr * 8, st, c->g_spec,
-                               c->g_tw, c->g_pairs, n_pairs, B, N, logL, (long)w0, out_scale, d_lag, d_frac, d_peak);
-            RMX_HIP(c, hipGetLastError());
-            continue;
-        }
-        const int l1 = c->g_logL1, l2 = c->g_logL2, L1 = 1 << l1, L2 = 1 << l2;
-        auto rows_grid = [](long rows, int R) -> dim3 {      // workgroups for `rows` rows of length R
-            const int tpr = gen_rows_tpr(R);
-            const int rpw = kGThreads / tpr;
-            return dim3((unsigned)((rows + rpw - 1) / rpw));
-        };
-        const int cthr = gen_cols_threads(l1);
-        const size_t clds = gen_cols_lds(l1), rlds = gen_rows_lds(L2);
-        // forward: column pass (zero-padded window -> [k1'][n2] * W_L^(n2 k1)), row pass (-> [k1'][k2'])
-        const int lt = col_log_t(l1), ntiles = L2 >> lt;
-#define RMX_COLS_FWD(U8V, LT)                                                                                          \
-    hipLaunchKernelGGL((g_cols_fwd<U8V, LT>), dim3(ntiles, items), dim3(cthr), clds, st, d_iq, c->g_spec, c->g_tw1, l1, l2, \
-                       first_item, c->g_lo_bits, c->g_thi, c->g_tlo)
-        if (u8) { if (lt == 3) RMX_COLS_FWD(true, 3); else RMX_COLS_FWD(true, 4); }
-        else    { if (lt == 3) RMX_COLS_FWD(false, 3); else RMX_COLS_FWD(false, 4); }
-#undef RMX_COLS_FWD
-        hipLaunchKernelGGL((g_rows<true, false, false>), rows_grid((long)items * L1, L2), dim3(kGThreads), rlds, st, c->g_spec,
-                           c->g_tw2, l2, L1, l1, L, c->g_lo_bits, c->g_thi, c->g_tlo, fwd_scale, (long)items * L1,
-                           (const float2*)nullptr, (const GPair*)nullptr, 0, 0, gen_rows_tpr(L2));
-        // pairs: row pass ([product on load] rows(L2)^-1 * conj W_L^(n2 k1)), column pass (-> r natural + partial argmax)
-        hipLaunchKernelGGL((g_rows<false, true, true>), rows_grid((long)slots * L1, L2), dim3(kGThreads), rlds, st,
-                           c->g_prod, c->g_tw2, l2, L1, l1, L, c->g_lo_bits, c->g_thi, c->g_tlo, 1.0f, (long)slots * L1,
-                           c->g_spec, c->g_pairs, n_pairs, B, gen_rows_tpr(L2));
-        if (lt == 3)
-            hipLaunchKernelGGL((g_cols_inv<3>), dim3(ntiles, slots), dim3(cthr), clds, st, c->g_prod, c->g_tw1, l1, l2, c->g_rec,
-                               c->g_halo);
-        else
-            hipLaunchKernelGGL((g_cols_inv<4>), dim3(ntiles, slots), dim3(cthr), clds, st, c->g_prod, c->g_tw1, l1, l2, c->g_rec,
-                               c->g_halo);
-        hipLaunchKernelGGL(g_final, dim3(slots), dim3(64), 0, st, N, l1, l2, lt, c->g_rec, c->g_halo, ntiles, slots,
-                           (long)w0 * n_pairs, out_scale, d_lag, d_frac, d_peak);
-        RMX_HIP(c, hipGetLastError());
+        rc = generic_forward(c, d_iq, w0, wc, u8, nullptr);
+        if (rc) return rc;
+        rc = generic_pairs(c, w0, wc, n_pairs, d_lag, d_frac, d_peak, false);
+        if (rc) return rc;
     }
     return RMX_OK;
 }
@@ -1646,7 +1664,7 @@ void rmx_destroy(rmx_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     for (void* p : {(void*)c->g_tw, (void*)c->g_tw1, (void*)c->g_tw2, (void*)c->g_thi, (void*)c->g_tlo, (void*)c->g_spec,
-                    (void*)c->g_prod, (void*)c->g_rec, (void*)c->g_halo, (void*)c->g_pairs})
+                    (void*)c->g_spec_r, (void*)c->g_prod, (void*)c->g_rec, (void*)c->g_halo, (void*)c->g_pairs})
         if (p) (void)hipFree(p);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     for (hipEvent_t e : c->copy_ev)
@@ -1655,8 +1673,7 @@ void rmx_destroy(rmx_ctx* c) {
         if (p) (void)hipFree(p);
     for (void* p : {(void*)c->sv_buoys, (void*)c->sv_pairs, c->sv_in, c->sv_out})
         if (p) (void)hipFree(p);
-    if (c->caf_child) rmx_destroy(c->caf_child);
-    for (void* p : {(void*)c->caf_aug, (void*)c->caf_rot, (void*)c->caf_lag, (void*)c->caf_frac, (void*)c->caf_peak,
+    for (void* p : {(void*)c->d_spec_r, (void*)c->caf_rot, (void*)c->caf_lag, (void*)c->caf_frac, (void*)c->caf_peak,
                     (void*)c->caf_dop})
         if (p) (void)hipFree(p);
     if (c->d_spec) (void)hipFree(c->d_spec);
@@ -1681,7 +1698,6 @@ int rmx_set_stream(rmx_ctx* c, void* hip_stream) {
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     c->stream = (hipStream_t)hip_stream;
     c->own_stream = false;
-    if (c->caf_child) return rmx_set_stream(c->caf_child, hip_stream);
     return RMX_OK;
 }
 
@@ -1753,6 +1769,68 @@ static int ensure_spec(rmx_ctx* c, long windows) {
     c->scratch_bytes += nb - c->spec_bytes;
     c->spec_bytes = nb;
     return RMX_OK;
+}
+
+// N = 4096, unfused path: forward spectra of windows [w0, w0 + wc) into d_spec (rot == nullptr) or, de-rotated by
+// the phasor table rot[N], into d_spec_r (rmx_caf_batch); then the pair kernels over the plan's pair list
+static int fwd4096(rmx_ctx* c, const void* d_iq, int w0, int wc, bool u8, const float2* rot) {
+    const long first_item = (long)w0 * c->n_buoys;
+    const int n_items = wc * c->n_buoys;
+    if (rot) {
+        const size_t nb = (size_t)(wc < c->chunk_windows ? c->chunk_windows : wc) * c->n_buoys * (8 * kThreads) * sizeof(float4);
+        if (c->spec_r_bytes < nb) {
+            RMX_HIP(c, hipStreamSynchronize(c->stream));
+            if (c->d_spec_r) (void)hipFree(c->d_spec_r);
+            c->d_spec_r = nullptr;
+            c->spec_r_bytes = 0;
+            RMX_HIP(c, hipMalloc((void**)&c->d_spec_r, nb));
+            c->spec_r_bytes = nb;
+        }
+    }
+    float4* dst = rot ? c->d_spec_r : c->d_spec;
+    if (c->timing) RMX_HIP(c, hipEventRecord(c->ev[c->ev_used], c->stream));
+    if (u8)
+        hipLaunchKernelGGL(k_fwd<true>, dim3(n_items), dim3(kThreads), kLdsBytes, c->stream, d_iq, dst, c->d_tw1, c->d_tw2,
+                           first_item, 1.0f, rot);
+    else
+        hipLaunchKernelGGL(k_fwd<false>, dim3(n_items), dim3(kThreads), kLdsBytes, c->stream, d_iq, dst, c->d_tw1, c->d_tw2,
+                           first_item, 1.0f, rot);
+    RMX_HIP(c, hipGetLastError());
+    if (c->timing) {
+        RMX_HIP(c, hipEventRecord(c->ev[c->ev_used + 1], c->stream));
+        c->ev_used += 2;
+        c->ev_kind.push_back(0);
+    }
+    return RMX_OK;
+}
+static int pairs4096(rmx_ctx* c, int w0, int wc, int n_pairs, int* d_lag, float* d_frac, float* d_peak, float out_scale,
+                     bool use_rot) {
+    const int n_parts = c->plan_n_parts;
+    const int xcd_map = (wc % 8 == 0) ? 1 : 0;
+    const float4* spec_j = use_rot ? c->d_spec_r : c->d_spec;
+    if (c->timing) RMX_HIP(c, hipEventRecord(c->ev[c->ev_used], c->stream));
+    if (c->resident)
+        hipLaunchKernelGGL(k_pair_res, dim3(wc * n_parts), dim3(kThreads), kLdsResBytes, c->stream, (const float4*)c->d_spec,
+                           spec_j, c->d_tw1, c->d_tw2, c->d_items, c->d_part_begin, n_parts, c->n_buoys, n_pairs, xcd_map,
+                           (long)w0, out_scale, d_lag, d_frac, d_peak, c->dbg);
+    else
+        hipLaunchKernelGGL(k_pair_str, dim3(wc * n_parts), dim3(kThreads), kLdsBytes, c->stream, (const float4*)c->d_spec, spec_j,
+                           c->d_tw1, c->d_tw2, c->d_items, c->d_part_begin, n_parts, c->n_buoys, n_pairs, xcd_map, (long)w0,
+                           out_scale, d_lag, d_frac, d_peak);
+    RMX_HIP(c, hipGetLastError());
+    if (c->timing) {
+        RMX_HIP(c, hipEventRecord(c->ev[c->ev_used + 1], c->stream));
+        c->ev_used += 2;
+        c->ev_kind.push_back(1);
+    }
+    return RMX_OK;
+}
+static float out_scale4096() {
+    // power-of-two scaling: the TW1 table carries 2^-6, so the spectra carry 2^-6, the product 2^-12 and
+    // the inverse transform (which uses the table once more) 2^-18; the taps get the remaining factor
+    int logl = 0;
+    while ((1 << logl) < kL) ++logl;
+    return std::ldexp(1.0f, 3 * kTw1ScaleLog2 - logl);
 }
 
 int rmx_xcorr_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pairs, int n_pairs,
@@ -1830,12 +1908,8 @@ int rmx_xcorr_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pa
         }
         return RMX_OK;
     }
-    // power-of-two scaling: the TW1 table carries 2^-6, so the spectra carry 2^-6, the product 2^-12 and
-    // the inverse transform (which uses the table once more) 2^-18; the taps get the remaining factor
-    int logl = 0;
-    while ((1 << logl) < kL) ++logl;
     const float fwd_scale = 1.0f;
-    const float out_scale = std::ldexp(1.0f, 3 * kTw1ScaleLog2 - logl);
+    const float out_scale = out_scale4096();
 
     {   // scratch: per workgroup for the fused kernel, per window of a chunk otherwise
         const bool fused_path = c->fused && c->plan_all_pairs;
@@ -1906,37 +1980,10 @@ int rmx_xcorr_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pa
             }
             continue;
         }
-        const long first_item = (long)w0 * c->n_buoys;
-        const int n_items = wc * c->n_buoys;
-        if (c->timing) RMX_HIP(c, hipEventRecord(c->ev[c->ev_used], c->stream));
-        if (u8)
-            hipLaunchKernelGGL(k_fwd<true>, dim3(n_items), dim3(kThreads), kLdsBytes, c->stream, d_iq, c->d_spec,
-                               c->d_tw1, c->d_tw2, first_item, fwd_scale);
-        else
-            hipLaunchKernelGGL(k_fwd<false>, dim3(n_items), dim3(kThreads), kLdsBytes, c->stream, d_iq, c->d_spec,
-                               c->d_tw1, c->d_tw2, first_item, fwd_scale);
-        RMX_HIP(c, hipGetLastError());
-        if (c->timing) {
-            RMX_HIP(c, hipEventRecord(c->ev[c->ev_used + 1], c->stream));
-            c->ev_used += 2;
-            c->ev_kind.push_back(0);
-            RMX_HIP(c, hipEventRecord(c->ev[c->ev_used], c->stream));
-        }
-        const int xcd_map = (wc % 8 == 0) ? 1 : 0;
-        if (c->resident)
-            hipLaunchKernelGGL(k_pair_res, dim3(wc * n_parts), dim3(kThreads), kLdsResBytes, c->stream, c->d_spec,
-                               c->d_tw1, c->d_tw2, c->d_items, c->d_part_begin, n_parts, c->n_buoys, n_pairs,
-                               xcd_map, (long)w0, out_scale, d_lag, d_frac, d_peak, c->dbg);
-        else
-            hipLaunchKernelGGL(k_pair_str, dim3(wc * n_parts), dim3(kThreads), kLdsBytes, c->stream, c->d_spec,
-                               c->d_tw1, c->d_tw2, c->d_items, c->d_part_begin, n_parts, c->n_buoys, n_pairs,
-                               xcd_map, (long)w0, out_scale, d_lag, d_frac, d_peak);
-        RMX_HIP(c, hipGetLastError());
-        if (c->timing) {
-            RMX_HIP(c, hipEventRecord(c->ev[c->ev_used + 1], c->stream));
-            c->ev_used += 2;
-            c->ev_kind.push_back(1);
-        }
+        rc = fwd4096(c, d_iq, w0, wc, u8, nullptr);
+        if (rc != RMX_OK) return rc;
+        rc = pairs4096(c, w0, wc, n_pairs, d_lag, d_frac, d_peak, out_scale, false);
+        if (rc != RMX_OK) return rc;
     }
     if (!out_dev) {
         RMX_HIP(c, hipMemcpyAsync(lag_int, d_lag, out_elems * sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -1957,29 +2004,16 @@ int rmx_caf_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pair
         return fail(c, RMX_E_INVAL, "n_windows %d not in 0..max_windows=%d", n_windows, c->max_windows);
     const int B = c->n_buoys, N = c->n_samples;
     const int all_pairs = B * (B - 1) / 2;
-    std::vector<int32_t> pl;
     if (!pairs) {
         if (n_pairs != 0 && n_pairs != all_pairs)
             return fail(c, RMX_E_INVAL, "pairs == NULL needs n_pairs == 0 or %d, got %d", all_pairs, n_pairs);
         n_pairs = all_pairs;
-        for (int i = 0; i < B; ++i)
-            for (int j = i + 1; j < B; ++j) { pl.push_back(i); pl.push_back(B + j); }
-    } else {
-        for (int q = 0; q < n_pairs; ++q) {
-            const int i = pairs[2 * q], j = pairs[2 * q + 1];
-            if (i < 0 || j < 0 || i >= B || j >= B) return fail(c, RMX_E_INVAL, "pair %d out of range", q);
-            pl.push_back(i);
-            pl.push_back(B + j);
-        }
     }
+    if (n_pairs < 0) return fail(c, RMX_E_INVAL, "n_pairs %d < 0", n_pairs);
     if (n_windows == 0 || n_pairs == 0) return RMX_OK;
     RMX_HIP(c, hipSetDevice(c->device));
-    if (!c->caf_child) {
-        int rc = rmx_create(&c->caf_child, c->device, 2 * B, N, c->max_windows, 0);
-        if (rc != RMX_OK) return fail(c, rc, "CAF child engine: %s", rmx_last_error(nullptr));
-        rc = rmx_set_stream(c->caf_child, (void*)c->stream);
-        if (rc != RMX_OK) return fail(c, rc, "CAF child stream");
-    }
+    int rc = build_plan(c, pairs, n_pairs);          // validates the pair list
+    if (rc != RMX_OK) return rc;
     const bool in_dev = flags & RMX_IN_DEVICE, out_dev = flags & RMX_OUT_DEVICE, u8 = flags & RMX_IN_U8;
     const size_t in_bytes = (size_t)n_windows * B * N * (u8 ? 2 : 8);
     const void* d_iq = iq;
@@ -1993,13 +2027,6 @@ int rmx_caf_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pair
         RMX_HIP(c, hipMemcpyAsync(c->d_in, iq, in_bytes, hipMemcpyHostToDevice, c->stream));
         d_iq = c->d_in;
     }
-    const size_t aug_bytes = (size_t)n_windows * 2 * B * N * sizeof(float2);
-    if (c->caf_aug_bytes < aug_bytes) {
-        if (c->caf_aug) (void)hipFree(c->caf_aug);
-        c->caf_aug = nullptr; c->caf_aug_bytes = 0;
-        RMX_HIP(c, hipMalloc((void**)&c->caf_aug, aug_bytes));
-        c->caf_aug_bytes = aug_bytes;
-    }
     // phasor table [D][N]: exp(-2 pi i nu n) in double, rounded once to float
     std::vector<double> grid(doppler_cps, doppler_cps + n_dopplers);
     if (grid != c->caf_grid || c->caf_rot_elems < (size_t)n_dopplers * N) {
@@ -2009,6 +2036,7 @@ int rmx_caf_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pair
                 const double a = -6.283185307179586476925286766559 * grid[d] * (double)n;
                 rot[(size_t)d * N + n] = make_float2((float)std::cos(a), (float)std::sin(a));
             }
+        RMX_HIP(c, hipStreamSynchronize(c->stream));
         if (c->caf_rot) (void)hipFree(c->caf_rot);
         c->caf_rot = nullptr; c->caf_rot_elems = 0;
         RMX_HIP(c, hipMalloc((void**)&c->caf_rot, rot.size() * sizeof(float2)));
@@ -2042,23 +2070,40 @@ int rmx_caf_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pair
         }
         b_dop = c->caf_dop; b_lag = c->d_lag; b_frac = c->d_frac; b_peak = c->d_peak;
     }
-    const int items = n_windows * B;
-    for (int d = 0; d < n_dopplers; ++d) {
-        const dim3 grid_aug((N + 255) / 256 > 64 ? 64 : (N + 255) / 256, items > 65535 ? 65535 : items);
-        if (u8)
-            hipLaunchKernelGGL(k_caf_augment<true>, grid_aug, dim3(256), 0, c->stream, d_iq, c->caf_rot + (size_t)d * N,
-                               c->caf_aug, B, N, (long)items);
-        else
-            hipLaunchKernelGGL(k_caf_augment<false>, grid_aug, dim3(256), 0, c->stream, d_iq, c->caf_rot + (size_t)d * N,
-                               c->caf_aug, B, N, (long)items);
-        RMX_HIP(c, hipGetLastError());
-        const int rc = rmx_xcorr_batch(c->caf_child, c->caf_aug, n_windows, pl.data(), n_pairs, c->caf_lag, c->caf_frac,
-                                       c->caf_peak, RMX_IN_DEVICE | RMX_OUT_DEVICE);
-        if (rc != RMX_OK) return fail(c, rc, "CAF bin %d: %s", d, rmx_last_error(c->caf_child));
-        hipLaunchKernelGGL(k_caf_select, dim3((unsigned)((out_elems + 255) / 256)), dim3(256), 0, c->stream, d,
-                           (int)out_elems, c->caf_lag, c->caf_frac, c->caf_peak, b_dop, b_lag, b_frac, b_peak);
-        RMX_HIP(c, hipGetLastError());
+    // Per chunk of windows: the un-rotated spectra once, then per hypothesis the de-rotated spectra (the rotation
+    // is applied as the window is loaded), the pair kernels with X_i un-rotated and X_j de-rotated, and the
+    // running d-major first maximum.  No augmented copy of the windows, no second engine.
+    const bool timing = c->timing;
+    c->timing = false;                    // (per-launch events are sized for rmx_xcorr_batch)
+    int chunk;
+    if (c->generic) {
+        rc = rmx::generic_ensure(c, n_pairs);
+        if (rc != RMX_OK) { c->timing = timing; return rc; }
+        chunk = c->g_chunk;
+    } else {
+        chunk = c->chunk_windows;
+        rc = ensure_spec(c, n_windows < chunk ? n_windows : chunk);
+        if (rc != RMX_OK) { c->timing = timing; return rc; }
     }
+    const float osc = out_scale4096();
+    for (int w0 = 0; w0 < n_windows && rc == RMX_OK; w0 += chunk) {
+        const int wc = n_windows - w0 < chunk ? n_windows - w0 : chunk;
+        rc = c->generic ? rmx::generic_forward(c, d_iq, w0, wc, u8, nullptr) : fwd4096(c, d_iq, w0, wc, u8, nullptr);
+        for (int d = 0; d < n_dopplers && rc == RMX_OK; ++d) {
+            const float2* rot = c->caf_rot + (size_t)d * N;
+            rc = c->generic ? rmx::generic_forward(c, d_iq, w0, wc, u8, rot) : fwd4096(c, d_iq, w0, wc, u8, rot);
+            if (rc != RMX_OK) break;
+            rc = c->generic ? rmx::generic_pairs(c, w0, wc, n_pairs, c->caf_lag, c->caf_frac, c->caf_peak, true)
+                            : pairs4096(c, w0, wc, n_pairs, c->caf_lag, c->caf_frac, c->caf_peak, osc, true);
+            if (rc != RMX_OK) break;
+            const long first = (long)w0 * n_pairs, cnt = (long)wc * n_pairs;
+            hipLaunchKernelGGL(k_caf_select, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, c->stream, d, first, cnt,
+                               c->caf_lag, c->caf_frac, c->caf_peak, b_dop, b_lag, b_frac, b_peak);
+            if (hipGetLastError() != hipSuccess) rc = fail(c, RMX_E_HIP, "k_caf_select launch failed");
+        }
+    }
+    c->timing = timing;
+    if (rc != RMX_OK) return rc;
     if (!out_dev) {
         RMX_HIP(c, hipMemcpyAsync(dop_idx, b_dop, out_elems * sizeof(int), hipMemcpyDeviceToHost, c->stream));
         RMX_HIP(c, hipMemcpyAsync(lag_int, b_lag, out_elems * sizeof(int), hipMemcpyDeviceToHost, c->stream));
