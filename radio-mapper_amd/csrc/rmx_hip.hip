@@ -732,9 +732,16 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
             float e0 = d.re[2 * j], e1 = d.im[2 * j], e2 = d.re[2 * j + 1], e3 = d.im[2 * j + 1];
             asm volatile("" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3));
             const u32x4 w = {__float_as_uint(e0), __float_as_uint(e1), __float_as_uint(e2), __float_as_uint(e3)};
-            // the whole byte offset goes into the VGPR offset: buffer STORES with a non-zero SGPR soffset
-            // corrupted the stored spectra on MI355X / ROCm 7.2 (nondeterministically; loads with an SGPR
-            // soffset are fine, and neither s_nop padding nor vmcnt(0) after the store cured it)
+            // The whole byte offset goes into the VGPR offset, soffset = 0.  Root cause of the corruption seen with
+            // an SGPR soffset (round 2, tools/exp_soffset.py + tools/probe/soffset_probe.hip): a store of more
+            // than 64 bits reads its data VGPRs late, so a VALU write to them needs a wait state behind the store
+            // (ISA "required software-inserted wait states").  hipcc 7.2's hazard recognizer waives that wait
+            // state when the store has an SGPR soffset, but on gfx950 the hazard is still there: with soffset in
+            // an SGPR the next group's `v_mov_b32 v3, v86` followed the store of v[2:5] directly and half of all
+            // pair-windows came out wrong on every call; the same stores with two wait states forced behind each
+            // (an asm that keeps e0..e3 live) were right 200 calls out of 200, as is this immediate-soffset form, for
+            // which the compiler inserts the s_nop itself.  (The SGPR form alone is fine: the probe, whose stores
+            // do not reuse their data registers, has no wrong float.)
             __builtin_amdgcn_raw_buffer_store_b128(w, ss, soff + (b * 8 + j) * (kThreads * 16), 0, 0);
         }
     };
