@@ -315,11 +315,14 @@ def main():
     eng.set_stream(stream.cuda_stream)
     eng.set_option("timing", 1)   # HIP events around every launch, on the launch stream
 
+    calls = [0]      # full-size engine calls made by this process (tools/summarize_prof.py divides counter totals by it)
     if caf:
         def step():
+            calls[0] += 1
             eng.caf_device(x.data_ptr(), W, grid, dop.data_ptr(), lag.data_ptr(), frac.data_ptr(), peak.data_ptr())
     else:
         def step():
+            calls[0] += 1
             eng.correlate_device(x.data_ptr(), W, lag.data_ptr(), frac.data_ptr(), peak.data_ptr())
 
     def sync_all():
@@ -378,6 +381,7 @@ def main():
         eng.correlate(xh[:64])
         th = time.perf_counter()
         eng.correlate(xh)
+        calls[0] += 1
         host_ms = (time.perf_counter() - th) * 1e3
         del xh
         step()                    # leave the device-pointer results of the timed path in lag/frac/peak
@@ -467,7 +471,7 @@ def main():
         line = {
             "metric": "IQ samples cross-correlated per second" + (" (pair-window-Doppler-bin samples)" if caf else ""),
             "value": value, "unit": unit, "n_gpus": n_gpus, "ranks_seen": seen, "steps": steps,
-            "warmup": warm, "prewarm_steps": prewarm, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "warmup": warm, "prewarm_steps": prewarm, "engine_calls": calls[0], "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": cfg["what"], "name": args.config,
                        "n_buoys": B, "n_pairs": P, "n_samples": N, "windows_per_gpu": W, "channels": C,

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Condense a tools/profile.sh output directory into profiles/<tag>_*.{csv,json}.
 
-  python tools/summarize_prof.py gpurun_out/prof_<tag> <tag>
+  python tools/summarize_prof.py gpurun_out/prof_<tag> <tag> [cfgN]
 
 Writes  profiles/<tag>_kernel_stats.csv   (rocprofv3 --kernel-trace --stats, our kernels only)
         profiles/<tag>_pmc.json           (per-kernel averages of every collected counter)
@@ -64,6 +64,30 @@ def main():
     pmc = {k: {c: sum(v) / len(v) for c, v in d.items()} | {"launches_sampled": len(next(iter(d.values())))}
            for k, d in agg.items()}
     json.dump(pmc, open(os.path.join(out, f"{tag}_pmc.json"), "w"), indent=1, sort_keys=True)
+    cfg = sys.argv[3] if len(sys.argv) > 3 else "cfg3"
+    if cfg != "cfg3":
+        # multi-kernel shapes: HBM bytes of ALL our kernels per engine call (= bench.py's step): counter totals over
+        # every dispatch of the FETCH_SIZE / WRITE_SIZE passes divided by the engine calls bench.py reports
+        tot = collections.defaultdict(float)
+        ncalls = {}
+        for cname in ("FETCH_SIZE", "WRITE_SIZE"):
+            for p in glob.glob(os.path.join(src, f"pmc_{cname}", "*counter_collection.csv")):
+                for r in csv.DictReader(open(p)):
+                    if any(k in r["Kernel_Name"] for k in ours) and r["Counter_Name"] == cname:
+                        tot[cname] += float(r["Counter_Value"])
+            log = os.path.join(src, f"pmc_{cname}.log")
+            for ln in open(log) if os.path.exists(log) else []:
+                if ln.startswith("{"):
+                    ncalls[cname] = json.loads(ln).get("engine_calls")
+        if tot and all(ncalls.get(k) for k in ("FETCH_SIZE", "WRITE_SIZE")):
+            f, w = tot["FETCH_SIZE"] / ncalls["FETCH_SIZE"], tot["WRITE_SIZE"] / ncalls["WRITE_SIZE"]
+            traffic = {"kernel": "all kernels of one engine call", "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0,
+                       "fetch_size_kib_raw": f, "write_size_kib": w, "engine_calls": ncalls,
+                       "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 64 B per 128-B request)", "tag": tag}
+            json.dump(traffic, open(os.path.join(out, f"traffic_{cfg}.json"), "w"), indent=1)
+            print(traffic)
+        print("kernels:", list(pmc))
+        return
     dom = max(pmc, key=lambda k: pmc[k].get("SQ_WAVE_CYCLES", 0)) if pmc else None
     if dom and "FETCH_SIZE" in pmc[dom] and "WRITE_SIZE" in pmc[dom]:
         fetch, write = pmc[dom]["FETCH_SIZE"], pmc[dom]["WRITE_SIZE"]
