@@ -109,9 +109,49 @@ __device__ __forceinline__ float2 tw_full(const float2* __restrict__ tw, int e, 
     const float2 w = tw[e & (half - 1)];
     return (e & half) ? make_float2(-w.x, -w.y) : w;
 }
-// DIF pass: M stages on blocks of 2^b (forward, W = exp(-2 pi i / R))
-template <int M, int LOGT>
-__device__ __forceinline__ void dif_pass(float2* x, int logR, int b, const float2* __restrict__ tw, int tid, int nthr) {
+// Where a pass reads its group from and writes it to.  A group's first element has the (unpadded) index
+// E0 = (j << LOGT) | c, its m-th element sits o = m * (q << LOGT) further on.
+struct LdsIO {      // the transform buffer in LDS, padded by lp()
+    float2* x;
+    struct H {
+        float2* p;
+        // lp(E0 + o) = lp(E0) + o + (o >> 4): E0's 16-block has fewer than the stride's worth of elements in front
+        // of E0 whenever the stride is below 16, and whole blocks are crossed otherwise
+        __device__ __forceinline__ float2 ld(int o) const { return p[o + (o >> 4)]; }
+        __device__ __forceinline__ void st(int o, float2 v) const { p[o + (o >> 4)] = v; }
+    };
+    __device__ __forceinline__ H open(int E0) const { return H{x + (E0 + (E0 >> 4))}; }
+};
+// adaptors: a pass end given as a callable on the element index (source) or on (E0, o, value) (sink)
+template <class F>
+struct SrcFn {
+    F f;
+    struct H {
+        const F& f;
+        int E0;
+        __device__ __forceinline__ float2 ld(int o) const { return f(E0 + o); }
+    };
+    __device__ __forceinline__ H open(int E0) const { return H{f, E0}; }
+};
+template <class F>
+struct DstFn {
+    F f;
+    struct H {
+        const F& f;
+        int E0;
+        __device__ __forceinline__ void st(int o, float2 v) const { f(E0, o, v); }
+    };
+    __device__ __forceinline__ H open(int E0) const { return H{f, E0}; }
+};
+template <class F>
+__device__ __forceinline__ SrcFn<F> make_src(F f) { return SrcFn<F>{f}; }
+template <class F>
+__device__ __forceinline__ DstFn<F> make_dst(F f) { return DstFn<F>{f}; }
+
+// DIF pass: M stages on blocks of 2^b (forward, W = exp(-2 pi i / R)); no barrier inside
+template <int M, int LOGT, class Src, class Dst>
+__device__ __forceinline__ void dif_pass(int logR, int b, const float2* __restrict__ tw, int tid, int nthr, const Src& src,
+                                         const Dst& dst) {
     constexpr int RAD = 1 << M, T = 1 << LOGT;
     const int qb = b - M, q = 1 << qb, half = 1 << (logR - 1);
     const int work = (1 << (logR - M)) << LOGT;
@@ -119,30 +159,29 @@ __device__ __forceinline__ void dif_pass(float2* x, int logR, int b, const float
         const int c = idx & (T - 1), i = idx >> LOGT;
         const int l = i & (q - 1);
         const int j = ((i >> qb) << b) | l;
-        float2* p = x + lp(((long)j << LOGT) + c);
+        const int E0 = (j << LOGT) + c;
         const int qs = q << LOGT;
-        // element m of the group: (m qs) further on, plus the padding crossed on the way (the group's first
-        // element has fewer than qs elements of its 16-block in front of it when qs < 16)
-        auto at = [&](int m) -> int { return m * qs + ((m * qs) >> 4); };
+        const auto hs = src.open(E0);
+        const auto hd = dst.open(E0);
         float2 v[RAD];
 #pragma unroll
-        for (int m = 0; m < RAD; ++m) v[m] = p[at(m)];
+        for (int m = 0; m < RAD; ++m) v[m] = hs.ld(m * qs);
         dft_reg<RAD>(v);
-        p[0] = v[0];
+        hd.st(0, v[0]);
         if (qb > 0) {
             const int es = l << (logR - b);
 #pragma unroll
-            for (int k = 1; k < RAD; ++k) p[at(brev_m<M>(k))] = g_cmul(v[k], tw_full(tw, es * k, half));
+            for (int k = 1; k < RAD; ++k) hd.st(brev_m<M>(k) * qs, g_cmul(v[k], tw_full(tw, es * k, half)));
         } else {
 #pragma unroll
-            for (int k = 1; k < RAD; ++k) p[at(brev_m<M>(k))] = v[k];
+            for (int k = 1; k < RAD; ++k) hd.st(brev_m<M>(k) * qs, v[k]);
         }
     }
-    __syncthreads();
 }
-// DIT pass with conjugated twiddles: the exact inverse data flow (unnormalised)
-template <int M, int LOGT>
-__device__ __forceinline__ void dit_pass(float2* x, int logR, int b, const float2* __restrict__ tw, int tid, int nthr) {
+// DIT pass with conjugated twiddles: the exact inverse data flow (unnormalised); no barrier inside
+template <int M, int LOGT, class Src, class Dst>
+__device__ __forceinline__ void dit_pass(int logR, int b, const float2* __restrict__ tw, int tid, int nthr, const Src& src,
+                                         const Dst& dst) {
     constexpr int RAD = 1 << M, T = 1 << LOGT;
     const int qb = b - M, q = 1 << qb, half = 1 << (logR - 1);
     const int work = (1 << (logR - M)) << LOGT;
@@ -150,51 +189,104 @@ __device__ __forceinline__ void dit_pass(float2* x, int logR, int b, const float
         const int c = idx & (T - 1), i = idx >> LOGT;
         const int l = i & (q - 1);
         const int j = ((i >> qb) << b) | l;
-        float2* p = x + lp(((long)j << LOGT) + c);
+        const int E0 = (j << LOGT) + c;
         const int qs = q << LOGT;
-        auto at = [&](int m) -> int { return m * qs + ((m * qs) >> 4); };
+        const auto hs = src.open(E0);
+        const auto hd = dst.open(E0);
         float2 v[RAD];      // (im, re)-swapped: swap o DFT o swap = conj(DFT)
         {
-            const float2 e = p[0];
+            const float2 e = hs.ld(0);
             v[0] = make_float2(e.y, e.x);
         }
         if (qb > 0) {
             const int es = l << (logR - b);
 #pragma unroll
             for (int k = 1; k < RAD; ++k) {
-                const float2 e = g_cmulc(p[at(brev_m<M>(k))], tw_full(tw, es * k, half));
+                const float2 e = g_cmulc(hs.ld(brev_m<M>(k) * qs), tw_full(tw, es * k, half));
                 v[k] = make_float2(e.y, e.x);
             }
         } else {
 #pragma unroll
             for (int k = 1; k < RAD; ++k) {
-                const float2 e = p[at(brev_m<M>(k))];
+                const float2 e = hs.ld(brev_m<M>(k) * qs);
                 v[k] = make_float2(e.y, e.x);
             }
         }
         dft_reg<RAD>(v);
 #pragma unroll
-        for (int m = 0; m < RAD; ++m) p[at(m)] = make_float2(v[m].y, v[m].x);
+        for (int m = 0; m < RAD; ++m) hd.st(m * qs, make_float2(v[m].y, v[m].x));
     }
-    __syncthreads();
 }
-// DIF: natural in -> bit-reversed out (forward).  Passes: radix 16 while four stages remain, then the rest.
+// run-time stage count -> the instantiated pass
+template <int LOGT, class Src, class Dst>
+__device__ __forceinline__ void dif_pass_m(int M, int logR, int b, const float2* __restrict__ tw, int tid, int nthr,
+                                           const Src& src, const Dst& dst) {
+    if (M == 4) dif_pass<4, LOGT>(logR, b, tw, tid, nthr, src, dst);
+    else if (M == 3) dif_pass<3, LOGT>(logR, b, tw, tid, nthr, src, dst);
+    else if (M == 2) dif_pass<2, LOGT>(logR, b, tw, tid, nthr, src, dst);
+    else dif_pass<1, LOGT>(logR, b, tw, tid, nthr, src, dst);
+}
+template <int LOGT, class Src, class Dst>
+__device__ __forceinline__ void dit_pass_m(int M, int logR, int b, const float2* __restrict__ tw, int tid, int nthr,
+                                           const Src& src, const Dst& dst) {
+    if (M == 4) dit_pass<4, LOGT>(logR, b, tw, tid, nthr, src, dst);
+    else if (M == 3) dit_pass<3, LOGT>(logR, b, tw, tid, nthr, src, dst);
+    else if (M == 2) dit_pass<2, LOGT>(logR, b, tw, tid, nthr, src, dst);
+    else dit_pass<1, LOGT>(logR, b, tw, tid, nthr, src, dst);
+}
+// Whole transforms with caller-supplied ends: the FIRST pass reads through `first`, the LAST writes through
+// `last`, everything between lives in the LDS buffer x.  With first / last = LdsIO{x} the transform is in place in
+// LDS; a kernel that passes its global source / sink here saves one LDS round trip and one barrier per end.
+// Passes: radix 16 while more than four stages remain, the rest (1..4 stages) in the last pass (DIF) or the first
+// (DIT).  A barrier follows every pass but the last.
+// DIF: natural in -> bit-reversed out (forward).
+template <int LOGT, class First, class Last>
+__device__ __forceinline__ void fft_dif(float2* x, int logR, const float2* __restrict__ tw, int tid, int nthr,
+                                        const First& first, const Last& last) {
+    const LdsIO mid{x};
+    int b = logR;
+    if (b <= 4) {
+        dif_pass_m<LOGT>(b, logR, b, tw, tid, nthr, first, last);
+        return;
+    }
+    dif_pass<4, LOGT>(logR, b, tw, tid, nthr, first, mid);
+    __syncthreads();
+    for (b -= 4; b > 4; b -= 4) {
+        dif_pass<4, LOGT>(logR, b, tw, tid, nthr, mid, mid);
+        __syncthreads();
+    }
+    dif_pass_m<LOGT>(b, logR, b, tw, tid, nthr, mid, last);
+}
+// DIT with conjugated twiddles: bit-reversed in -> natural out (inverse, unnormalised)
+template <int LOGT, class First, class Last>
+__device__ __forceinline__ void fft_dit_inv(float2* x, int logR, const float2* __restrict__ tw, int tid, int nthr,
+                                            const First& first, const Last& last) {
+    const LdsIO mid{x};
+    if (logR <= 4) {
+        dit_pass_m<LOGT>(logR, logR, logR, tw, tid, nthr, first, last);
+        return;
+    }
+    int b = ((logR - 1) & 3) + 1;            // stages of the first pass: what radix 16 leaves over (1..4)
+    dit_pass_m<LOGT>(b, logR, b, tw, tid, nthr, first, mid);
+    __syncthreads();
+    for (b += 4; b < logR; b += 4) {
+        dit_pass<4, LOGT>(logR, b, tw, tid, nthr, mid, mid);
+        __syncthreads();
+    }
+    dit_pass<4, LOGT>(logR, logR, tw, tid, nthr, mid, last);
+}
+// in place in LDS, barrier behind the last pass too
 template <int LOGT = 0>
 __device__ __forceinline__ void lds_dif(float2* x, int logR, const float2* __restrict__ tw, int tid, int nthr) {
-    int b = logR;
-    for (; b >= 4; b -= 4) dif_pass<4, LOGT>(x, logR, b, tw, tid, nthr);
-    if (b == 3) dif_pass<3, LOGT>(x, logR, b, tw, tid, nthr);
-    else if (b == 2) dif_pass<2, LOGT>(x, logR, b, tw, tid, nthr);
-    else if (b == 1) dif_pass<1, LOGT>(x, logR, b, tw, tid, nthr);
+    const LdsIO io{x};
+    fft_dif<LOGT>(x, logR, tw, tid, nthr, io, io);
+    __syncthreads();
 }
-// DIT with conjugated twiddles: bit-reversed in -> natural out (inverse, unnormalised): the same passes backwards
 template <int LOGT = 0>
 __device__ __forceinline__ void lds_dit_inv(float2* x, int logR, const float2* __restrict__ tw, int tid, int nthr) {
-    const int r = logR & 3;
-    if (r == 3) dit_pass<3, LOGT>(x, logR, r, tw, tid, nthr);
-    else if (r == 2) dit_pass<2, LOGT>(x, logR, r, tw, tid, nthr);
-    else if (r == 1) dit_pass<1, LOGT>(x, logR, r, tw, tid, nthr);
-    for (int b = r + 4; b <= logR; b += 4) dit_pass<4, LOGT>(x, logR, b, tw, tid, nthr);
+    const LdsIO io{x};
+    fft_dit_inv<LOGT>(x, logR, tw, tid, nthr, io, io);
+    __syncthreads();
 }
 
 // 'full' order index (lag ascending from -(N-1)) of circular index m of an L = 2N point correlation;
@@ -364,46 +456,51 @@ __global__ __launch_bounds__(kGThreads) void g_rows(float2* __restrict__ data, c
     for (int k = threadIdx.x; k < (R >> 1); k += kGThreads) twl[k] = tw[k];
     float2* row = data + ridx * R;
     const int rib = (int)(ridx & (n_rows - 1));   // row index inside its batch element (n_rows = 2^row_bits)
-    if (live) {
-        if constexpr (PROD) {
+    static_assert((FWD && !TW && !PROD) || (!FWD && TW && PROD), "the two row passes of the four-step");
+    const LdsIO lds{x};
+    if constexpr (FWD) {
+        // forward rows: the first pass reads the row straight from HBM (its 2^M inputs are R / 2^M apart, so
+        // consecutive threads read consecutive elements), the last leaves the spectrum in LDS for the store loop
+        __syncthreads();                          // W_R table
+        fft_dif<0>(x, logR, twl, tid, tpr, make_src([&](int E) -> float2 { return live ? row[E] : make_float2(0.f, 0.f); }), lds);
+        __syncthreads();
+        if (!live) return;
+        batched<8>(tid, R, tpr, [&](int n) -> float2 { return x[lp(n)]; },
+                   [&](int n, float2 e) { row[n] = make_float2(e.x * scale, e.y * scale); });
+    } else {
+        // inverse rows: X_j conj(X_i) formed on load (the product never exists in HBM); the last pass hands its
+        // outputs -- 2^M values R / 2^M apart, consecutive threads consecutive elements -- to the twiddle and
+        // straight to HBM
+        const int a = logR >> 1, n1 = 1 << a, n2 = R >> a;
+        float2* t1 = reinterpret_cast<float2*>(gsm) + (long)(kGThreads / tpr) * lp(R) + (long)g * (n1 + n2);
+        float2* t2 = t1 + n1;
+        {   // W_L^(c*e) for this row's multiplier c and every exponent e < R = T1[e & (2^a - 1)] * T2[e >> a]
+            const long c = (long)brev(rib, row_bits);
+            for (int e = tid; e < n1 + n2; e += tpr) {
+                const long ee = e < n1 ? (long)e : ((long)(e - n1) << a);
+                t1[e] = big_tw((c * ee) & (Ltot - 1), lo_bits, thi, tlo);
+            }
+        }
+        if (live) {
             const long slot = ridx >> row_bits;
             const int wl = (int)(slot / n_pairs), q = (int)(slot % n_pairs);
             const GPair pr = pairs[q];
             const float2* xi = spec + (((long)wl * n_buoys + pr.i) * n_rows + rib) * R;
             const float2* xj = spec_j + (((long)wl * n_buoys + pr.j) * n_rows + rib) * R;
-            batched<4>(tid, R, tpr, [&](int n) -> float4 { const float2 a = xj[n], b = xi[n]; return make_float4(a.x, a.y, b.x, b.y); },
+            batched<4>(tid, R, tpr, [&](int n) -> float4 { const float2 u = xj[n], v = xi[n]; return make_float4(u.x, u.y, v.x, v.y); },
                        [&](int n, float4 v) { x[lp(n)] = g_cmulc(make_float2(v.x, v.y), make_float2(v.z, v.w)); });
-        } else {
-            batched<8>(tid, R, tpr, [&](int n) -> float2 { return row[n]; }, [&](int n, float2 v) { x[lp(n)] = v; });
-        }
-    }
-    __syncthreads();
-    if (FWD) lds_dif(x, logR, twl, tid, tpr); else lds_dit_inv(x, logR, twl, tid, tpr);
-    if constexpr (TW) {
-        // W_L^(c*e) for this row's fixed multiplier c and every exponent e < R, as the product of two
-        // per-row LDS tables T1[e & (2^a - 1)] * T2[e >> a] (2^a + R/2^a big-table lookups per row
-        // instead of two uncoalesced gathers per element)
-        const int a = logR >> 1, n1 = 1 << a, n2 = R >> a;
-        float2* t1 = reinterpret_cast<float2*>(gsm) + (long)(kGThreads / tpr) * lp(R) + (long)g * (n1 + n2);
-        float2* t2 = t1 + n1;
-        const long c = FWD ? (long)rib : (long)brev(rib, row_bits);
-        for (int e = tid; e < n1 + n2; e += tpr) {
-            const long ee = e < n1 ? (long)e : ((long)(e - n1) << a);
-            t1[e] = big_tw((c * ee) & (Ltot - 1), lo_bits, thi, tlo);
         }
         __syncthreads();
+        fft_dit_inv<0>(x, logR, twl, tid, tpr, lds, lds);
+        __syncthreads();
         if (!live) return;
+        // (measured on cfg2: the last pass straight to HBM through the twiddle 1.73 ms, this loop batched eight
+        // deep 2.05 ms, plain 1.68 ms: the kernel already moves 5.7 TB/s with the second read of every spectrum
+        // served on die)
         for (int n = tid; n < R; n += tpr) {
-            const int e = FWD ? brev(n, logR) : n;
-            const float2 w = g_cmul(t1[e & (n1 - 1)], t2[e >> a]);
-            const float2 v = FWD ? g_cmul(x[lp(n)], w) : g_cmulc(x[lp(n)], w);
-            row[n] = make_float2(v.x * scale, v.y * scale);
-        }
-    } else {
-        if (!live) return;
-        for (int n = tid; n < R; n += tpr) {
-            const float2 e = x[lp(n)];
-            row[n] = make_float2(e.x * scale, e.y * scale);
+            const float2 w = g_cmul(t1[n & (n1 - 1)], t2[n >> a]);
+            const float2 r = g_cmulc(x[lp(n)], w);
+            row[n] = make_float2(r.x * scale, r.y * scale);
         }
     }
 }
@@ -431,42 +528,45 @@ __global__ __launch_bounds__(1024) void g_cols_fwd(const void* __restrict__ iq, 
     const long L = (long)L1 << l2, N = L >> 1;
     const int c0 = blockIdx.x * kColT;
     const long item = first_item + blockIdx.y;
-    float2* twl = x + lp((long)L1 << kColLogT) + (long)kColT * ((1 << (l1 >> 1)) + (L1 >> (l1 >> 1)));   // behind x and the tables
-    for (int k = tid; k < (L1 >> 1); k += nthr) twl[k] = tw[k];
-    const int nz = (L1 >> 1) << kColLogT;                     // only the rows n1 < L1/2 are non-zero
-    for (int idx = nz + tid; idx < (L1 << kColLogT); idx += nthr) x[lp(idx)] = make_float2(0.f, 0.f);
-    batched<8>(tid, nz, nthr,
-               [&](int idx) -> float2 {
-                   const long n = (long)(idx >> kColLogT) * L2 + c0 + (idx & (kColT - 1));
-                   if constexpr (U8) {
-                       const uchar2 b = reinterpret_cast<const uchar2*>(iq)[item * N + n];
-                       return make_float2((float)b.x - 127.5f, (float)b.y - 127.5f);
-                   } else {
-                       return reinterpret_cast<const float2*>(iq)[item * N + n];
-                   }
-               },
-               [&](int idx, float2 v) {
-                   x[lp(idx)] = rot ? rot_mul(v, rot[(long)(idx >> kColLogT) * L2 + c0 + (idx & (kColT - 1))]) : v;
-               });
-    __syncthreads();
-    lds_dif<kColLogT>(x, l1, twl, tid, nthr);
-    // per-column twiddle tables: W_L^(n2*e) = T1[e & (2^a-1)] * T2[e >> a]   (n2*e < L: no reduction)
+    // per-column twiddle tables W_L^(n2*e) = T1[e & (2^a-1)] * T2[e >> a] (n2*e < L: no reduction) and the W_L1 table
     const int a = l1 >> 1, na = 1 << a, nb = L1 >> a;
-    float2* tab = x + lp((long)L1 << kColLogT);             // [16][na + nb]
+    float2* tab = x + lp((long)L1 << kColLogT);             // [T][na + nb]
+    float2* twl = tab + (long)kColT * (na + nb);
+    for (int k = tid; k < (L1 >> 1); k += nthr) twl[k] = tw[k];
     for (int idx = tid; idx < kColT * (na + nb); idx += nthr) {
         const int c = idx / (na + nb), e = idx % (na + nb);
         const long ee = e < na ? (long)e : ((long)(e - na) << a);
         tab[idx] = big_tw((long)(c0 + c) * ee, lo_bits, thi, tlo);
     }
     __syncthreads();
+    // (first pass from HBM / last pass to HBM measured slower here: 2.0 vs 1.58 ms on cfg2 -- the sink's table
+    // lookups on top of a radix-16 pass spill)
+    const int nz = (L1 >> 1) << kColLogT;                     // only the rows n1 < L1/2 are non-zero
+    for (int idx = nz + tid; idx < (L1 << kColLogT); idx += nthr) x[lp(idx)] = make_float2(0.f, 0.f);
+    batched<8>(tid, nz, nthr,
+               [&](int idx) -> float2 {
+                   const long n = (long)(idx >> kColLogT) * L2 + c0 + (idx & (kColT - 1));
+                   float2 v;
+                   if constexpr (U8) {
+                       const uchar2 b8 = reinterpret_cast<const uchar2*>(iq)[item * N + n];
+                       v = make_float2((float)b8.x - 127.5f, (float)b8.y - 127.5f);
+                   } else {
+                       v = reinterpret_cast<const float2*>(iq)[item * N + n];
+                   }
+                   return rot ? rot_mul(v, rot[n]) : v;
+               },
+               [&](int idx, float2 v) { x[lp(idx)] = v; });
+    __syncthreads();
+    lds_dif<kColLogT>(x, l1, twl, tid, nthr);
     float2* o = out + (long)blockIdx.y * L;
-    for (int idx = tid; idx < (L1 << kColLogT); idx += nthr) {
-        const int c = idx & (kColT - 1), pos = idx >> kColLogT;
-        const int k1 = brev(pos, l1);
-        const float2* tc = tab + c * (na + nb);
-        const float2 w = g_cmul(tc[k1 & (na - 1)], tc[na + (k1 >> a)]);
-        o[(long)pos * L2 + c0 + c] = g_cmul(x[lp(idx)], w);
-    }
+    batched<8>(tid, L1 << kColLogT, nthr, [&](int idx) -> float2 { return x[lp(idx)]; },
+               [&](int idx, float2 v) {
+                   const int c = idx & (kColT - 1), pos = idx >> kColLogT;
+                   const int k1 = brev(pos, l1);
+                   const float2* tc = tab + c * (na + nb);
+                   const float2 w = g_cmul(tc[k1 & (na - 1)], tc[na + (k1 >> a)]);
+                   o[(long)pos * L2 + c0 + c] = g_cmul(v, w);
+               });
 }
 // inverse: in[k1'][n2] (after the inverse row pass and its twiddle) -> this tile of r[n1][n2] in LDS only: the
 // tile's partial argmax of |r|^2 in 'full' order with the peak's two neighbour taps when they sit inside the
@@ -492,26 +592,29 @@ __global__ __launch_bounds__(1024) void g_cols_inv(const float2* __restrict__ in
     int* sk = reinterpret_cast<int*>(sv + 16);
     for (int k = tid; k < (L1 >> 1); k += nthr) twl[k] = tw[k];
     const float2* src = in + (long)blockIdx.y * L;
-    batched<8>(tid, L1 << kColLogT, nthr,
-               [&](int idx) -> float2 { return src[(long)(idx >> kColLogT) * L2 + c0 + (idx & (kColT - 1))]; },
-               [&](int idx, float2 v) { x[lp(idx)] = v; });
-    __syncthreads();
-    lds_dit_inv<kColLogT>(x, l1, twl, tid, nthr);
     float best = -1.0f;
     int bk = 0x7fffffff;
-    for (int idx = tid; idx < (L1 << kColLogT); idx += nthr) {
-        const long m = (long)(idx >> kColLogT) * L2 + c0 + (idx & (kColT - 1));
-        const float2 e = x[lp(idx)];
-        const int k = full_index((int)m, N);
-        const float v = e.x * e.x + e.y * e.y;
-        if (k >= 0 && (v > best || (v == best && k < bk))) { best = v; bk = k; }
-    }
+    // first pass straight from HBM (a thread's 2^M inputs are neighbouring rows of one column; consecutive
+    // threads take consecutive columns: the same row segments a tile load would fetch); the last pass never
+    // stores r: every output goes into the thread's running (max |r|^2, lowest 'full' index) and leaves only its
+    // |r|^2 in the buffer, for the taps and the halo
+    fft_dit_inv<kColLogT>(
+        x, l1, twl, tid, nthr,
+        make_src([&](int E) -> float2 { return src[(long)(E >> kColLogT) * L2 + c0 + (E & (kColT - 1))]; }),
+        make_dst([&](int E0, int off, float2 e) {
+            const int E = E0 + off;
+            const long m = (long)(E >> kColLogT) * L2 + c0 + (E & (kColT - 1));
+            const int k = full_index((int)m, N);
+            const float v = e.x * e.x + e.y * e.y;
+            if (k >= 0 && (v > best || (v == best && k < bk))) { best = v; bk = k; }
+            x[E0 + (E0 >> 4) + off + (off >> 4)] = make_float2(v, 0.0f);
+        }));
+    __syncthreads();
     // halo: |r|^2 of columns c0 and c0 + T - 1, all rows: [slot][tile][2][L1]
     float* hb = halo + ((long)blockIdx.y * gridDim.x + blockIdx.x) * 2L * L1;
     for (int n1 = tid; n1 < 2 * L1; n1 += nthr) {
         const int row = n1 & (L1 - 1), col = n1 < L1 ? 0 : kColT - 1;
-        const float2 e = x[lp((row << kColLogT) + col)];
-        hb[n1] = e.x * e.x + e.y * e.y;
+        hb[n1] = x[lp((row << kColLogT) + col)].x;
     }
     block_argmax_w(best, bk, sv, sk, tid, nthr);
     if (tid == 0) {
@@ -524,8 +627,8 @@ __global__ __launch_bounds__(1024) void g_cols_inv(const float2* __restrict__ in
             const int c = (int)(m & (L2 - 1)) - c0, row = (int)(m >> l2);
             // 'full' neighbours are the circular neighbours m -+ 1 (the excluded lag -N sits between the two
             // ends of the 'full' range): inside this tile when the column is
-            if (c > 0) { const float2 e = x[lp((row << kColLogT) + c - 1)]; t.tm = e.x * e.x + e.y * e.y; }
-            if (c < kColT - 1) { const float2 e = x[lp((row << kColLogT) + c + 1)]; t.tp = e.x * e.x + e.y * e.y; }
+            if (c > 0) t.tm = x[lp((row << kColLogT) + c - 1)].x;
+            if (c < kColT - 1) t.tp = x[lp((row << kColLogT) + c + 1)].x;
         }
         rec[(long)blockIdx.y * gridDim.x + blockIdx.x] = t;
     }
