@@ -237,8 +237,8 @@ __device__ __forceinline__ void dit_pass_m(int M, int logR, int b, const float2*
 // Whole transforms with caller-supplied ends: the FIRST pass reads through `first`, the LAST writes through
 // `last`, everything between lives in the LDS buffer x.  With first / last = LdsIO{x} the transform is in place in
 // LDS; a kernel that passes its global source / sink here saves one LDS round trip and one barrier per end.
-// Passes: radix 16 while more than four stages remain, the rest (1..4 stages) in the last pass (DIF) or the first
-// (DIT).  A barrier follows every pass but the last.
+// Passes: radix 16 while more than four stages remain, the rest (1..4 stages) in the last pass.  A barrier
+// follows every pass but the last.
 // DIF: natural in -> bit-reversed out (forward).
 template <int LOGT, class First, class Last>
 __device__ __forceinline__ void fft_dif(float2* x, int logR, const float2* __restrict__ tw, int tid, int nthr,
@@ -266,14 +266,15 @@ __device__ __forceinline__ void fft_dit_inv(float2* x, int logR, const float2* _
         dit_pass_m<LOGT>(logR, logR, logR, tw, tid, nthr, first, last);
         return;
     }
-    int b = ((logR - 1) & 3) + 1;            // stages of the first pass: what radix 16 leaves over (1..4)
-    dit_pass_m<LOGT>(b, logR, b, tw, tid, nthr, first, mid);
-    __syncthreads();
-    for (b += 4; b < logR; b += 4) {
-        dit_pass<4, LOGT>(logR, b, tw, tid, nthr, mid, mid);
+    // radix 16 first (a first pass that reads from HBM has 16 loads in flight per thread), what is left over
+    // (1..4 stages) in the last pass
+    int b = 0;
+    for (; b + 4 < logR; b += 4) {
+        if (b == 0) dit_pass<4, LOGT>(logR, 4, tw, tid, nthr, first, mid);
+        else dit_pass<4, LOGT>(logR, b + 4, tw, tid, nthr, mid, mid);
         __syncthreads();
     }
-    dit_pass<4, LOGT>(logR, logR, tw, tid, nthr, mid, last);
+    dit_pass_m<LOGT>(logR - b, logR, logR, tw, tid, nthr, mid, last);
 }
 // in place in LDS, barrier behind the last pass too
 template <int LOGT = 0>
