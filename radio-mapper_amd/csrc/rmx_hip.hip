@@ -1378,7 +1378,11 @@ static int generic_init(rmx_ctx* c) {
         RMX_HIP(c, hipFuncSetAttribute((const void*)g_fwd_small<true>, hipFuncAttributeMaxDynamicSharedMemorySize, slds));
     } else {
         // columns of length L1 <= 1024 (a tile of 16 columns is L1*128 bytes of LDS), rows of L2 = L/L1 <= 8192
-        c->g_logL1 = c->g_logL / 2 < 10 ? c->g_logL / 2 : 10;
+        // columns a little shorter than rows (measured: 512 x 4096 beats 1024 x 2048 at L = 2^21, 256 x 2048 beats
+        // 512 x 1024 at 2^19), rows at most 8192 (64 KiB of LDS)
+        c->g_logL1 = (c->g_logL - 3) / 2;
+        if (c->g_logL1 < c->g_logL - 13) c->g_logL1 = c->g_logL - 13;
+        if (c->g_logL1 > 10) c->g_logL1 = 10;
         if (const char* e = getenv("RMX_LOGL1")) { const int v = atoi(e); if (v >= 4 && v <= 10 && c->g_logL - v <= 13 && c->g_logL - v >= 4) c->g_logL1 = v; }
         c->g_logL2 = c->g_logL - c->g_logL1;
         c->g_lo_bits = (c->g_logL + 1) / 2;
