@@ -609,6 +609,22 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
     const int hl = lane < 2 ? lane : lane - 60;            // halo row of lanes 0,1,62,63
     const bool is_halo = lane < 2 || lane >= 62;
     __syncthreads();
+#ifndef RMX_TW2_LDS
+    // this thread's TW2 row W_256^(n0*k1), k1 = 0..15, kept in registers for the whole launch (30 of the 60 VGPRs
+    // this kernel left unused at 2 waves per SIMD) instead of eight ds_read_b128 per transform: LDS array time is
+    // not hidden behind the butterflies in this kernel, so the 11 % of it that these reads
+    // were came off the launch time one for one (1.778 -> 1.728 ms); -DRMX_TW2_LDS restores the LDS reads
+    C16 tw2r;
+    {
+        const float2* rowf2 = reinterpret_cast<const float2*>(tw2row);
+        tw2r.set(0, 1.0f, 0.0f);
+#pragma unroll
+        for (int q = 1; q < 16; ++q) {
+            const float2 w = rowf2[4 * (q & 3) + (q >> 2) - 1];
+            tw2r.set(q, w.x, w.y);
+        }
+    }
+#endif
 
     // persistent workgroup: the tables above are loaded once, then windows blockIdx.x, +gridDim.x, ...
     for (int wl = blockIdx.x; wl < n_win; wl += gridDim.x) {
@@ -758,13 +774,19 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
         barrier_hook(false);
         if (!(dbg & 8)) xchg_b_read(img, x, t);
         dft16(x);
+#ifdef RMX_TW2_LDS
         const float4 r0 = tw2row[0], r1 = tw2row[1];   // ahead of the exchange reads (see dft16_tw_row_l1)
+#endif
         if (!(dbg & 4)) {
         xchg_bc_write_b(img, x, t);
         wave_lds_order();
         xchg_bc_read_c(img, x, t);
         }
+#ifndef RMX_TW2_LDS
+        dft16_tw<true>(x, tw2r);
+#else
         dft16_tw_row(x, tw2row, r0, r1);   // W_256^(n0*k1) as pre-twiddle of the last pass
+#endif
 #pragma unroll
         for (int q = 0; q < 16; ++q) xc.set(q, x[q].x, x[q].y);   // (scaled by 2^-6 through the TW1 table)
         ++seq;
@@ -804,12 +826,18 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
                 if (!(dbg & 16)) prefetch(kac);
             });
         }
+#ifdef RMX_TW2_LDS
         const float4 r0 = tw2row[0], r1 = tw2row[1];   // ahead of the exchange reads (see dft16_tw_row_l1)
+#endif
         if (!(dbg & 4)) {
             wave_lds_order();
             xchg_bc_read_b(img, v, t);
         }
+#ifndef RMX_TW2_LDS
+        dft16_tw_l1<true>(v, tw2r);
+#else
         dft16_tw_row_l1(v, tw2row, r0, r1);      // W_256^(n0*k1), k1 -> n1   (role B), layer 1
+#endif
         {
             float2* xb = img + (u >> 4) * kBcHalf + (u & 15) * 2 + p;   // own half-wave regions
             dft16_layer2_emit(v, [&](auto kac, const float2& x0, const float2& x1, const float2& x2, const float2& x3)
