@@ -577,7 +577,7 @@ template <bool U8>
 __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq_v, float4* __restrict__ spec,
                                                      const float4* __restrict__ tw1_g,
                                                      const float2* __restrict__ tw2_g, int n_buoys,
-                                                     long first_window, float fwd_scale, float out_scale,
+                                                     long first_window, float out_scale,
                                                      int* __restrict__ lag_int, float* __restrict__ lag_frac,
                                                      float* __restrict__ peak, int n_win, int dbg_rt, int stag) {
 #ifdef RMX_ABLATE
@@ -719,14 +719,6 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
                 const unsigned r = __float_as_uint(d.re[q]);
                 d.set(q, (float)(r & 0xffu) - 127.5f, (float)(r >> 8) - 127.5f);
             }
-        }
-    };
-    auto load_spec = [&](C16& d, int b) __attribute__((always_inline)) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(ss, soff, (b * 8 + j) * (kThreads * 16), 0);
-            d.set(2 * j, __uint_as_float(w.x), __uint_as_float(w.y));
-            d.set(2 * j + 1, __uint_as_float(w.z), __uint_as_float(w.w));
         }
     };
     auto load_spec_part = [&](C16& d, int b, auto part) __attribute__((always_inline)) {
@@ -1947,8 +1939,7 @@ int rmx_xcorr_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pa
         }
         return RMX_OK;
     }
-    const float fwd_scale = 1.0f;
-    const float out_scale = out_scale4096();
+    const float out_scale = out_scale4096();   // (the forward scale 2^-6 rides on the TW1 table)
 
     {   // scratch: per workgroup for the fused kernel, per window of a chunk otherwise
         const bool fused_path = c->fused && c->plan_all_pairs;
@@ -1956,7 +1947,6 @@ int rmx_xcorr_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pa
         rc = ensure_spec(c, fused_path ? (chunk_w < c->n_cus ? chunk_w : c->n_cus) : chunk_w);
         if (rc != RMX_OK) return rc;
     }
-    const int n_parts = c->plan_n_parts;
     const int n_chunks = (n_windows + c->chunk_windows - 1) / c->chunk_windows;
     c->ev_used = 0;
     c->ev_kind.clear();
@@ -2004,11 +1994,11 @@ int rmx_xcorr_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pa
                                            c->d_tw1, c->d_tw2, c->n_buoys, wfirst, out_scale, d_lag, d_frac, d_peak, sc);
                 } else if (u8)
                     hipLaunchKernelGGL(k_win<true>, dim3(wgrid), dim3(kThreads), kLdsWinBytes, c->stream, d_iq, c->d_spec,
-                                       c->d_tw1, c->d_tw2, c->n_buoys, wfirst, fwd_scale, out_scale, d_lag, d_frac,
+                                       c->d_tw1, c->d_tw2, c->n_buoys, wfirst, out_scale, d_lag, d_frac,
                                        d_peak, sc, c->dbg, c->stag);
                 else
                     hipLaunchKernelGGL(k_win<false>, dim3(wgrid), dim3(kThreads), kLdsWinBytes, c->stream, d_iq, c->d_spec,
-                                       c->d_tw1, c->d_tw2, c->n_buoys, wfirst, fwd_scale, out_scale, d_lag, d_frac,
+                                       c->d_tw1, c->d_tw2, c->n_buoys, wfirst, out_scale, d_lag, d_frac,
                                        d_peak, sc, c->dbg, c->stag);
                 RMX_HIP(c, hipGetLastError());
                 if (c->timing) {
