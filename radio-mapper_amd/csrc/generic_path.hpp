@@ -448,30 +448,32 @@ __global__ __launch_bounds__(kGThreads) void g_rows(float2* __restrict__ data, c
     const int tpr = tpr_arg > 0 ? tpr_arg : rows_tpr(R);                               // threads per row
     const int rpw = kGThreads / tpr;                                                   // rows per workgroup
     const int g = threadIdx.x / tpr, tid = threadIdx.x % tpr;
-    const long ridx = (long)blockIdx.x * rpw + g;
-    const bool live = ridx < total_rows;
     float2* x = reinterpret_cast<float2*>(gsm) + (long)g * lp(R);
-    // the row's twiddle table goes to LDS once (butterflies would otherwise fetch two entries per
-    // radix-4 group through the vector memory path, a dependent cache-latency access in the inner loop)
+    // the W_R table goes to LDS once per (persistent) workgroup (butterflies would otherwise fetch their twiddles
+    // through the vector memory path, a dependent cache-latency access in the inner loop)
     float2* twl = reinterpret_cast<float2*>(gsm) + (long)rpw * lp(R) + (TW ? (long)rpw * ((1 << (logR >> 1)) + (R >> (logR >> 1))) : 0);
     for (int k = threadIdx.x; k < (R >> 1); k += kGThreads) twl[k] = tw[k];
-    float2* row = data + ridx * R;
-    const int rib = (int)(ridx & (n_rows - 1));   // row index inside its batch element (n_rows = 2^row_bits)
     static_assert((FWD && !TW && !PROD) || (!FWD && TW && PROD), "the two row passes of the four-step");
     const LdsIO lds{x};
+    const long n_blocks = (total_rows + rpw - 1) / rpw;
+    __syncthreads();                              // W_R table
+    // persistent: the workgroup walks blocks of rpw rows blockIdx.x, + gridDim.x, ... (the table above is half the
+    // size of a row: loading it per row was a third of this kernel's L2 traffic)
+    for (long blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+    const long ridx = blk * rpw + g;
+    const bool live = ridx < total_rows;
+    float2* row = data + ridx * R;
+    const int rib = (int)(ridx & (n_rows - 1));   // row index inside its batch element (n_rows = 2^row_bits)
     if constexpr (FWD) {
         // forward rows: the first pass reads the row straight from HBM (its 2^M inputs are R / 2^M apart, so
         // consecutive threads read consecutive elements), the last leaves the spectrum in LDS for the store loop
-        __syncthreads();                          // W_R table
         fft_dif<0>(x, logR, twl, tid, tpr, make_src([&](int E) -> float2 { return live ? row[E] : make_float2(0.f, 0.f); }), lds);
         __syncthreads();
-        if (!live) return;
-        batched<8>(tid, R, tpr, [&](int n) -> float2 { return x[lp(n)]; },
-                   [&](int n, float2 e) { row[n] = make_float2(e.x * scale, e.y * scale); });
+        if (live)
+            batched<8>(tid, R, tpr, [&](int n) -> float2 { return x[lp(n)]; },
+                       [&](int n, float2 e) { row[n] = make_float2(e.x * scale, e.y * scale); });
     } else {
-        // inverse rows: X_j conj(X_i) formed on load (the product never exists in HBM); the last pass hands its
-        // outputs -- 2^M values R / 2^M apart, consecutive threads consecutive elements -- to the twiddle and
-        // straight to HBM
+        // inverse rows: X_j conj(X_i) formed on load (the product never exists in HBM)
         const int a = logR >> 1, n1 = 1 << a, n2 = R >> a;
         float2* t1 = reinterpret_cast<float2*>(gsm) + (long)(kGThreads / tpr) * lp(R) + (long)g * (n1 + n2);
         float2* t2 = t1 + n1;
@@ -494,14 +496,144 @@ __global__ __launch_bounds__(kGThreads) void g_rows(float2* __restrict__ data, c
         __syncthreads();
         fft_dit_inv<0>(x, logR, twl, tid, tpr, lds, lds);
         __syncthreads();
-        if (!live) return;
         // (measured on cfg2: the last pass straight to HBM through the twiddle 1.73 ms, this loop batched eight
-        // deep 2.05 ms, plain 1.68 ms: the kernel already moves 5.7 TB/s with the second read of every spectrum
-        // served on die)
-        for (int n = tid; n < R; n += tpr) {
-            const float2 w = g_cmul(t1[n & (n1 - 1)], t2[n >> a]);
-            const float2 r = g_cmulc(x[lp(n)], w);
-            row[n] = make_float2(r.x * scale, r.y * scale);
+        // deep 2.05 ms, plain 1.68 ms)
+        if (live)
+            for (int n = tid; n < R; n += tpr) {
+                const float2 w = g_cmul(t1[n & (n1 - 1)], t2[n >> a]);
+                const float2 r = g_cmulc(x[lp(n)], w);
+                row[n] = make_float2(r.x * scale, r.y * scale);
+            }
+    }
+    __syncthreads();                              // the next block's first pass / tables overwrite x, t1
+    }
+}
+
+// ---- both row passes in one kernel (few buoys) ---------------------------------------------------------------
+// The inverse row pass of pair (i, j) needs row `rib` of X_i and X_j only, and that row of a spectrum is the forward
+// row transform of row `rib` of the column pass's output.  With few buoys a workgroup therefore does everything for
+// one (window, rib): the NB forward row transforms, whose LAST pass -- a radix-16 butterfly on 16 neighbouring
+// elements per thread -- ends in registers (NB x 16 complex per thread: the register file is the larger memory, 512
+// KiB per CU against 160 KiB of LDS), then for every pair the product out of those registers straight into the
+// FIRST pass of the inverse (the same 16 neighbours), the remaining passes in LDS and the twiddled store.  The
+// spectra are never written: per window (3 NB + 3 P) L x 8 bytes of HBM traffic instead of (5 NB + 5 P) L x 8 for
+// the whole four-step (cfg2: 14.4 GB instead of 24 GB).  R / 16 threads per row; the scale of the forward
+// transform (a power of two) is applied once, squared, at the store.
+// Passes on the way down to the 16-point blocks (DIF) / up from them (DIT): radix 16, with the 1..3 left-over
+// stages in a first radix-8 / 4 / 2 pass (8 then 4 for five stages).
+__device__ __forceinline__ int fused_pass_m(int left) {
+    const int r = left & 3;
+    return r == 0 ? 4 : (r == 1 && left > 1 ? 3 : r);
+}
+template <class First>
+__device__ __forceinline__ void fft_dif_to_regs(float2* x, int logR, const float2* __restrict__ tw, int tid, int nthr,
+                                                const First& first, float2 (&out)[16]) {
+    const LdsIO mid{x};
+    int b = logR;
+    if (b > 4) {
+        const int M = fused_pass_m(b - 4);
+        dif_pass_m<0>(M, logR, b, tw, tid, nthr, first, mid);
+        __syncthreads();
+        b -= M;
+    }
+    while (b > 4) {
+        const int M = fused_pass_m(b - 4);
+        dif_pass_m<0>(M, logR, b, tw, tid, nthr, mid, mid);
+        __syncthreads();
+        b -= M;
+    }
+    const auto h = mid.open(tid << 4);
+#pragma unroll
+    for (int m = 0; m < 16; ++m) out[m] = h.ld(m);
+    dft16(out);         // out[k] belongs at position 16 tid + bitrev4(k): the inverse's first pass reads it as its input k
+}
+// v[k]: the (unswapped) input k of the thread's first DIT butterfly; result in LDS (natural order)
+__device__ __forceinline__ void fft_dit_inv_from_regs(float2* x, int logR, const float2* __restrict__ tw, int tid, int nthr,
+                                                      float2 (&v)[16]) {
+    const LdsIO mid{x};
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = make_float2(v[k].y, v[k].x);
+    dft16(v);
+    const auto h = mid.open(tid << 4);
+#pragma unroll
+    for (int m = 0; m < 16; ++m) h.st(m, make_float2(v[m].y, v[m].x));
+    __syncthreads();
+    for (int b = 4; b < logR;) {
+        const int M = fused_pass_m(logR - b);
+        dit_pass_m<0>(M, logR, b + M, tw, tid, nthr, mid, mid);
+        __syncthreads();
+        b += M;
+    }
+}
+template <int NB>
+__device__ __forceinline__ void constexpr_pair(int ij, const float2 (&S)[NB][16], float2 (&v)[16]) {
+    const int i = ij / NB, j = ij % NB;       // constant after unrolling
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = g_cmulc(S[j][k], S[i][k]);
+}
+template <int NB>
+__global__ __launch_bounds__(kGThreads, 2) void g_rows_fused(const float2* __restrict__ cols, float2* __restrict__ prod,
+                                                          const float2* __restrict__ tw, int logR, int n_rows, int row_bits,
+                                                          long Ltot, int lo_bits, const float2* __restrict__ thi,
+                                                          const float2* __restrict__ tlo, float scale, long n_units,
+                                                          const GPair* __restrict__ pairs, int n_pairs) {
+    extern __shared__ __attribute__((aligned(16))) char gsm[];
+    const int R = 1 << logR, tpr = R >> 4, upw = kGThreads / tpr;     // threads per row, (window, rib) units per workgroup
+    const int g = threadIdx.x / tpr, tid = threadIdx.x % tpr;
+    const int a = logR >> 1, n1 = 1 << a, n2 = R >> a;
+    float2* x = reinterpret_cast<float2*>(gsm) + (long)g * lp(R);
+    float2* t1 = reinterpret_cast<float2*>(gsm) + (long)upw * lp(R) + (long)g * (n1 + n2);
+    float2* t2 = t1 + n1;
+    float2* twl = reinterpret_cast<float2*>(gsm) + (long)upw * (lp(R) + n1 + n2);
+    for (int k = threadIdx.x; k < (R >> 1); k += kGThreads) twl[k] = tw[k];
+    const long n_blocks = (n_units + upw - 1) / upw;
+    __syncthreads();
+    for (long blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+        const long unit = blk * upw + g;
+        const bool live = unit < n_units;
+        const int rib = (int)(unit & (n_rows - 1));
+        const long wl = unit >> row_bits;
+        {   // W_L^(c*e), c = this row's multiplier: T1[e & (2^a - 1)] * T2[e >> a] (as g_rows)
+            const long c = (long)brev(rib, row_bits);
+            for (int e = tid; e < n1 + n2; e += tpr) {
+                const long ee = e < n1 ? (long)e : ((long)(e - n1) << a);
+                t1[e] = big_tw((c * ee) & (Ltot - 1), lo_bits, thi, tlo);
+            }
+        }
+        float2 S[NB][16];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const float2* row = cols + (((long)wl * NB + b) * n_rows + rib) * R;
+            int tl = tid;                         // (opaque copy: keeps the passes' address arithmetic inside the loop --
+            asm volatile("" : "+v"(tl));          // hoisted out of the persistent loop it costs ~100 VGPRs and spills)
+            fft_dif_to_regs(x, logR, twl, tl, tpr, make_src([&](int E) -> float2 { return live ? row[E] : make_float2(0.f, 0.f); }), S[b]);
+            __syncthreads();                      // the next transform's first pass overwrites x
+        }
+        for (int q = 0; q < n_pairs; ++q) {
+            const GPair pr = pairs[q];
+            float2 v[16];
+            // the pair's two spectra: register arrays cannot be indexed at run time, so one (workgroup-uniform)
+            // branch per ordered pair
+            const int code = pr.i * NB + pr.j;
+            constexpr_pair<NB>(0, S, v);          // (defined on every path: no value carried around the pair loop)
+#pragma unroll
+            for (int ij = 1; ij < NB * NB; ++ij)
+                if (code == ij) {
+                    asm volatile("" ::: "memory");    // keeps the branch: hipcc otherwise computes all NB^2 products and selects
+                    constexpr_pair<NB>(ij, S, v);
+                }
+            int tl = tid;
+            asm volatile("" : "+v"(tl));
+            fft_dit_inv_from_regs(x, logR, twl, tl, tpr, v);
+            if (live) {
+                float2* row = prod + (((long)wl * n_pairs + q) * n_rows + rib) * R;
+                for (int n = tl; n < R; n += tpr) {
+                    const float2 w = g_cmul(t1[n & (n1 - 1)], t2[n >> a]);
+                    const float2 r = g_cmulc(x[lp(n)], w);
+                    row[n] = make_float2(r.x * scale, r.y * scale);
+                }
+            }
+            __syncthreads();                      // x (and, behind the last pair, t1) are rewritten
         }
     }
 }

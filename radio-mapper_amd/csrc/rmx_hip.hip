@@ -1173,6 +1173,8 @@ struct rmx_ctx {
     // generic path (n_samples != 4096): see generic_path.hpp
     bool generic = false;
     int g_logL = 0, g_logL1 = 0, g_logL2 = 0, g_lo_bits = 0, g_chunk = 0;
+    bool g_fused = false;      // four-step: both row passes in g_rows_fused (n_buoys <= 4, plain batches)
+    int g_fused_wgs = 0;       // its persistent grid
     float2 *g_tw = nullptr, *g_tw1 = nullptr, *g_tw2 = nullptr, *g_thi = nullptr, *g_tlo = nullptr;
     float2 *g_spec = nullptr, *g_spec_r = nullptr, *g_prod = nullptr;   // spectra, de-rotated spectra (CAF), products
     rmx::gen::GTile* g_rec = nullptr;   // per column tile: partial argmax + taps
@@ -1369,6 +1371,12 @@ static size_t gen_rows_lds(int R) {                     // rows + per-row twiddl
     const int a = logR >> 1;
     return ((size_t)(gen::kGThreads / tpr) * ((size_t)gen::lp(R) + (1 << a) + (R >> a)) + (size_t)(R >> 1)) * 8;   // + W_R table
 }
+static size_t gen_fused_lds(int R) {                    // g_rows_fused: R/16 threads per row
+    int logR = 0;
+    while ((1 << logR) < R) ++logR;
+    const int a = logR >> 1, tpr = R >> 4, upw = gen::kGThreads / (tpr > 0 ? tpr : 1);
+    return ((size_t)upw * ((size_t)gen::lp(R) + (1 << a) + (R >> a)) + (size_t)(R >> 1)) * 8;
+}
 static size_t gen_cols_lds(int l1) {                    // [L1][T] tile + T per-column twiddle tables
     const int a = l1 >> 1, T = 1 << gen::col_log_t(l1);
     return ((size_t)gen::lp((long)(1 << l1) * T) + (size_t)T * ((1 << a) + ((1 << l1) >> a)) + (size_t)((1 << l1) >> 1)) * 8;   // + W_L1 table
@@ -1427,6 +1435,17 @@ static int generic_init(rmx_ctx* c) {
         RMX_HIP(c, hipFuncSetAttribute((const void*)(g_cols_inv<4>), hipFuncAttributeMaxDynamicSharedMemorySize, cols_lds));
         RMX_HIP(c, hipFuncSetAttribute((const void*)(g_rows<true, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, rows_lds));
         RMX_HIP(c, hipFuncSetAttribute((const void*)(g_rows<false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, rows_lds));
+        // both row passes in one kernel when the buoys' spectra rows fit the register file (generic_path.hpp)
+        c->g_fused = c->n_buoys <= 4 && c->g_logL2 >= 5 && c->g_logL2 <= 12;
+        if (const char* e = getenv("RMX_FUSED")) c->g_fused = c->g_fused && atoi(e) != 0;
+        if (c->g_fused) {
+            const int flds = (int)gen_fused_lds(1 << c->g_logL2);
+            const void* fn = c->n_buoys == 2 ? (const void*)g_rows_fused<2> : c->n_buoys == 3 ? (const void*)g_rows_fused<3> : (const void*)g_rows_fused<4>;
+            RMX_HIP(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, flds));
+            int per_cu = 0;
+            RMX_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kGThreads, (size_t)flds));
+            c->g_fused_wgs = (per_cu > 0 ? per_cu : 1) * c->n_cus;
+        }
     }
     // windows per chunk: spectra (B*L) + products (P*L), 8 bytes each, under 32 GiB of the 288 (cfg2's 64
     // windows of 2^20 samples are one chunk of 6.4 GB)
@@ -1473,9 +1492,25 @@ static int generic_ensure(rmx_ctx* c, int n_pairs) {
     return RMX_OK;
 }
 
+// grid of the row kernels. Rows of 4096 points and more run persistent (as many workgroups as fit on the chip, each
+// loading the W_R table once: cfg2 5.79 -> 5.60 ms); shorter rows measured 2 % slower that way (L = 2^19: 1.56 vs
+// 1.59 ms) and keep one workgroup per block of rows.
+static dim3 rows_grid(const rmx_ctx* c, long rows, int rpw, size_t lds, int logR) {
+    const long blocks = (rows + rpw - 1) / rpw;
+    bool persist = logR >= 12;
+    if (const char* e = getenv("RMX_ROWS_PERSIST")) persist = atoi(e) != 0;
+    if (!persist) return dim3((unsigned)blocks);
+    long per_cu = (long)(160 * 1024 / (lds > 0 ? lds : 1));
+    if (per_cu > 8) per_cu = 8;
+    if (per_cu < 1) per_cu = 1;
+    const long resident = per_cu * c->n_cus;
+    return dim3((unsigned)(blocks < resident ? blocks : resident));
+}
+
 // forward spectra of windows [w0, w0 + wc) of d_iq into g_spec (rot == nullptr) or, de-rotated by the phasor
 // table rot[N], into g_spec_r (rmx_caf_batch)
-static int generic_forward(rmx_ctx* c, const void* d_iq, int w0, int wc, bool u8, const float2* rot) {
+static int generic_forward(rmx_ctx* c, const void* d_iq, int w0, int wc, bool u8, const float2* rot,
+                           bool cols_only = false) {
     using namespace gen;
     const int N = c->n_samples, logL = c->g_logL, B = c->n_buoys;
     const long L = 1L << logL;
@@ -1510,9 +1545,13 @@ static int generic_forward(rmx_ctx* c, const void* d_iq, int w0, int wc, bool u8
     if (u8) { if (lt == 3) RMX_COLS_FWD(true, 3); else RMX_COLS_FWD(true, 4); }
     else    { if (lt == 3) RMX_COLS_FWD(false, 3); else RMX_COLS_FWD(false, 4); }
 #undef RMX_COLS_FWD
+    if (cols_only) {                      // g_rows_fused does the rows
+        RMX_HIP(c, hipGetLastError());
+        return RMX_OK;
+    }
     const long rows = (long)items * L1;
     const int rpw = kGThreads / tpr;
-    hipLaunchKernelGGL((g_rows<true, false, false>), dim3((unsigned)((rows + rpw - 1) / rpw)), dim3(kGThreads), rlds, st, dst,
+    hipLaunchKernelGGL((g_rows<true, false, false>), rows_grid(c, rows, rpw, rlds, l2), dim3(kGThreads), rlds, st, dst,
                        c->g_tw2, l2, L1, l1, L, c->g_lo_bits, c->g_thi, c->g_tlo, fwd_scale, rows, (const float2*)nullptr,
                        (const float2*)nullptr, (const GPair*)nullptr, 0, 0, tpr);
     RMX_HIP(c, hipGetLastError());
@@ -1522,7 +1561,7 @@ static int generic_forward(rmx_ctx* c, const void* d_iq, int w0, int wc, bool u8
 // pair kernels of that chunk: X_i from g_spec, X_j from g_spec (use_rot false) or g_spec_r; results at
 // [(w0 + wl) * n_pairs + q] of the three output arrays
 static int generic_pairs(rmx_ctx* c, int w0, int wc, int n_pairs, int* d_lag, float* d_frac, float* d_peak,
-                         bool use_rot) {
+                         bool use_rot, bool fused = false) {
     using namespace gen;
     const int N = c->n_samples, logL = c->g_logL, B = c->n_buoys;
     const long L = 1L << logL;
@@ -1545,7 +1584,21 @@ static int generic_pairs(rmx_ctx* c, int w0, int wc, int n_pairs, int* d_lag, fl
     const long rows = (long)slots * L1;
     const int rpw = kGThreads / tpr;
     // row pass ([product on load] rows(L2)^-1 * conj W_L^(n2 k1)), column pass (-> tile records + halo), reduction
-    hipLaunchKernelGGL((g_rows<false, true, true>), dim3((unsigned)((rows + rpw - 1) / rpw)), dim3(kGThreads), rlds, st, c->g_prod,
+    if (fused) {
+        // g_spec holds the column pass's output: forward rows, products and inverse rows in one kernel
+        const long units = (long)wc * L1;
+        const int upw = kGThreads / (L2 >> 4 > 0 ? L2 >> 4 : 1);
+        const long blocks = (units + upw - 1) / upw;
+        const dim3 grid((unsigned)(blocks < c->g_fused_wgs ? blocks : c->g_fused_wgs));
+        const float fs = std::ldexp(1.0f, -(logL / 2));
+#define RMX_FUSED(NB)                                                                                                  \
+    hipLaunchKernelGGL((g_rows_fused<NB>), grid, dim3(kGThreads), gen_fused_lds(L2), st, (const float2*)c->g_spec,    \
+                       c->g_prod, c->g_tw2, l2, L1, l1, L, c->g_lo_bits, c->g_thi, c->g_tlo, fs * fs, units, c->g_pairs, \
+                       n_pairs)
+        if (B == 2) RMX_FUSED(2); else if (B == 3) RMX_FUSED(3); else RMX_FUSED(4);
+#undef RMX_FUSED
+    } else
+    hipLaunchKernelGGL((g_rows<false, true, true>), rows_grid(c, rows, rpw, rlds, l2), dim3(kGThreads), rlds, st, c->g_prod,
                        c->g_tw2, l2, L1, l1, L, c->g_lo_bits, c->g_thi, c->g_tlo, 1.0f, rows, (const float2*)c->g_spec, spec_j,
                        c->g_pairs, n_pairs, B, tpr);
     if (lt == 3)
@@ -1566,9 +1619,10 @@ static int generic_batch(rmx_ctx* c, const void* d_iq, int n_windows, int n_pair
     if (rc) return rc;
     for (int w0 = 0; w0 < n_windows; w0 += c->g_chunk) {
         const int wc = n_windows - w0 < c->g_chunk ? n_windows - w0 : c->g_chunk;
-        rc = generic_forward(c, d_iq, w0, wc, u8, nullptr);
+        const bool fused = c->g_fused && (1L << c->g_logL) > kGenSmallMaxL;
+        rc = generic_forward(c, d_iq, w0, wc, u8, nullptr, fused);
         if (rc) return rc;
-        rc = generic_pairs(c, w0, wc, n_pairs, d_lag, d_frac, d_peak, false);
+        rc = generic_pairs(c, w0, wc, n_pairs, d_lag, d_frac, d_peak, false, fused);
         if (rc) return rc;
     }
     return RMX_OK;
