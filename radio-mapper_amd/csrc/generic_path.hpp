@@ -521,35 +521,60 @@ __global__ __launch_bounds__(kGThreads) void g_rows(float2* __restrict__ data, c
 // transform (a power of two) is applied once, squared, at the store.
 // Passes on the way down to the 16-point blocks (DIF) / up from them (DIT): radix 16, with the 1..3 left-over
 // stages in a first radix-8 / 4 / 2 pass (8 then 4 for five stages).
-__device__ __forceinline__ int fused_pass_m(int left) {
-    const int r = left & 3;
-    return r == 0 ? 4 : (r == 1 && left > 1 ? 3 : r);
+// The kernel is compiled per row length (LOGR = 9..12): block sizes, strides and trip counts are constants, LDS
+// offsets immediates.
+__host__ __device__ constexpr int fused_pass_m(int left) {
+    return (left & 3) == 0 ? 4 : ((left & 3) == 1 && left > 1 ? 3 : (left & 3));
 }
-template <class First>
-__device__ __forceinline__ void fft_dif_to_regs(float2* x, int logR, const float2* __restrict__ tw, int tid, int nthr,
-                                                const First& first, float2 (&out)[16]) {
+// The thread's 16 raw inputs of a row's FIRST pass (radix 2^M on the whole row: butterfly idx = tid + it * nthr takes
+// the elements idx + m * R / 2^M) sit in registers, raw[it * 2^M + m], loaded by the caller -- all rows of a unit at
+// once, one HBM latency per unit instead of one per row, in the registers that later hold the spectra.
+template <int LOGR, int M>
+__device__ __forceinline__ void dif_first_from_regs(float2* x, const float2* __restrict__ tw, int tid, const float2 (&raw)[16]) {
+    constexpr int RAD = 1 << M, NIT = 16 / RAD, q = 1 << (LOGR - M), half = 1 << (LOGR - 1), nthr = 1 << (LOGR - 4);
     const LdsIO mid{x};
-    int b = logR;
-    if (b > 4) {
-        const int M = fused_pass_m(b - 4);
-        dif_pass_m<0>(M, logR, b, tw, tid, nthr, first, mid);
-        __syncthreads();
-        b -= M;
-    }
-    while (b > 4) {
-        const int M = fused_pass_m(b - 4);
-        dif_pass_m<0>(M, logR, b, tw, tid, nthr, mid, mid);
-        __syncthreads();
-        b -= M;
-    }
-    const auto h = mid.open(tid << 4);
 #pragma unroll
-    for (int m = 0; m < 16; ++m) out[m] = h.ld(m);
-    dft16(out);         // out[k] belongs at position 16 tid + bitrev4(k): the inverse's first pass reads it as its input k
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = tid + it * nthr;
+        const auto hd = mid.open(idx);
+        float2 v[RAD];
+#pragma unroll
+        for (int m = 0; m < RAD; ++m) v[m] = raw[it * RAD + m];
+        dft_reg<RAD>(v);
+        hd.st(0, v[0]);
+#pragma unroll
+        for (int k = 1; k < RAD; ++k) hd.st(brev_m<M>(k) * q, g_cmul(v[k], tw_full(tw, idx * k, half)));
+    }
+}
+// passes from blocks of 2^B down to the 16-point blocks, whose butterfly ends in registers
+template <int LOGR, int B>
+__device__ __forceinline__ void fft_dif_rest_to_regs(float2* x, const float2* __restrict__ tw, int tid, float2 (&out)[16]) {
+    const LdsIO mid{x};
+    if constexpr (B > 4) {
+        constexpr int M = fused_pass_m(B - 4);
+        dif_pass<M, 0>(LOGR, B, tw, tid, 1 << (LOGR - 4), mid, mid);
+        __syncthreads();
+        fft_dif_rest_to_regs<LOGR, B - M>(x, tw, tid, out);
+    } else {
+        const auto h = mid.open(tid << 4);
+#pragma unroll
+        for (int m = 0; m < 16; ++m) out[m] = h.ld(m);
+        dft16(out);     // out[k] belongs at position 16 tid + bitrev4(k): the inverse's first pass reads it as its input k
+    }
+}
+template <int LOGR, int B>
+__device__ __forceinline__ void fft_dit_rest(float2* x, const float2* __restrict__ tw, int tid) {
+    if constexpr (B < LOGR) {
+        const LdsIO mid{x};
+        constexpr int M = fused_pass_m(LOGR - B);
+        dit_pass<M, 0>(LOGR, B + M, tw, tid, 1 << (LOGR - 4), mid, mid);
+        __syncthreads();
+        fft_dit_rest<LOGR, B + M>(x, tw, tid);
+    }
 }
 // v[k]: the (unswapped) input k of the thread's first DIT butterfly; result in LDS (natural order)
-__device__ __forceinline__ void fft_dit_inv_from_regs(float2* x, int logR, const float2* __restrict__ tw, int tid, int nthr,
-                                                      float2 (&v)[16]) {
+template <int LOGR>
+__device__ __forceinline__ void fft_dit_inv_from_regs(float2* x, const float2* __restrict__ tw, int tid, float2 (&v)[16]) {
     const LdsIO mid{x};
 #pragma unroll
     for (int k = 0; k < 16; ++k) v[k] = make_float2(v[k].y, v[k].x);
@@ -558,12 +583,7 @@ __device__ __forceinline__ void fft_dit_inv_from_regs(float2* x, int logR, const
 #pragma unroll
     for (int m = 0; m < 16; ++m) h.st(m, make_float2(v[m].y, v[m].x));
     __syncthreads();
-    for (int b = 4; b < logR;) {
-        const int M = fused_pass_m(logR - b);
-        dit_pass_m<0>(M, logR, b + M, tw, tid, nthr, mid, mid);
-        __syncthreads();
-        b += M;
-    }
+    fft_dit_rest<LOGR, 4>(x, tw, tid);
 }
 template <int NB>
 __device__ __forceinline__ void constexpr_pair(int ij, const float2 (&S)[NB][16], float2 (&v)[16]) {
@@ -571,28 +591,43 @@ __device__ __forceinline__ void constexpr_pair(int ij, const float2 (&S)[NB][16]
 #pragma unroll
     for (int k = 0; k < 16; ++k) v[k] = g_cmulc(S[j][k], S[i][k]);
 }
-template <int NB>
+template <int NB, int LOGR>
 __global__ __launch_bounds__(kGThreads, 2) void g_rows_fused(const float2* __restrict__ cols, float2* __restrict__ prod,
-                                                          const float2* __restrict__ tw, int logR, int n_rows, int row_bits,
+                                                          const float2* __restrict__ tw, int n_rows, int row_bits,
                                                           long Ltot, int lo_bits, const float2* __restrict__ thi,
                                                           const float2* __restrict__ tlo, float scale, long n_units,
                                                           const GPair* __restrict__ pairs, int n_pairs) {
     extern __shared__ __attribute__((aligned(16))) char gsm[];
-    const int R = 1 << logR, tpr = R >> 4, upw = kGThreads / tpr;     // threads per row, (window, rib) units per workgroup
+    constexpr int R = 1 << LOGR, tpr = R >> 4, upw = kGThreads / tpr;   // threads per row, (window, rib) units per workgroup
+    constexpr int M0 = fused_pass_m(LOGR - 4);                          // stages of the forward rows' first pass
+    constexpr int a = LOGR >> 1, n1 = 1 << a, n2 = R >> a;
     const int g = threadIdx.x / tpr, tid = threadIdx.x % tpr;
-    const int a = logR >> 1, n1 = 1 << a, n2 = R >> a;
-    float2* x = reinterpret_cast<float2*>(gsm) + (long)g * lp(R);
-    float2* t1 = reinterpret_cast<float2*>(gsm) + (long)upw * lp(R) + (long)g * (n1 + n2);
+    float2* x = reinterpret_cast<float2*>(gsm) + g * (int)lp(R);
+    float2* t1 = reinterpret_cast<float2*>(gsm) + upw * (int)lp(R) + g * (n1 + n2);
     float2* t2 = t1 + n1;
-    float2* twl = reinterpret_cast<float2*>(gsm) + (long)upw * (lp(R) + n1 + n2);
+    float2* twl = reinterpret_cast<float2*>(gsm) + upw * ((int)lp(R) + n1 + n2);
     for (int k = threadIdx.x; k < (R >> 1); k += kGThreads) twl[k] = tw[k];
     const long n_blocks = (n_units + upw - 1) / upw;
     __syncthreads();
     for (long blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
-        const long unit = blk * upw + g;
-        const bool live = unit < n_units;
-        const int rib = (int)(unit & (n_rows - 1));
-        const long wl = unit >> row_bits;
+        // the block's units are rows rib0 .. rib0 + upw - 1 of one window (upw divides n_rows); addresses below are a
+        // workgroup-uniform base (SGPRs) plus a 32-bit offset per thread
+        const long unit0 = blk * upw;
+        const bool live = unit0 + g < n_units;
+        const int rib0 = (int)(unit0 & (n_rows - 1)), rib = rib0 + g;
+        const long wl = unit0 >> row_bits;
+        const unsigned goff = (unsigned)g << LOGR;
+        float2 S[NB][16];
+        {   // every row's first-pass inputs, all loads in flight together
+            constexpr int RAD = 1 << M0, qq = R >> M0;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const float2* row = cols + (((long)wl * NB + b) * n_rows + rib0) * R;
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    S[b][e] = live ? row[goff + (unsigned)(tid + (e / RAD) * tpr + (e % RAD) * qq)] : make_float2(0.f, 0.f);
+            }
+        }
         {   // W_L^(c*e), c = this row's multiplier: T1[e & (2^a - 1)] * T2[e >> a] (as g_rows)
             const long c = (long)brev(rib, row_bits);
             for (int e = tid; e < n1 + n2; e += tpr) {
@@ -600,13 +635,14 @@ __global__ __launch_bounds__(kGThreads, 2) void g_rows_fused(const float2* __res
                 t1[e] = big_tw((c * ee) & (Ltot - 1), lo_bits, thi, tlo);
             }
         }
-        float2 S[NB][16];
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            const float2* row = cols + (((long)wl * NB + b) * n_rows + rib) * R;
-            int tl = tid;                         // (opaque copy: keeps the passes' address arithmetic inside the loop --
-            asm volatile("" : "+v"(tl));          // hoisted out of the persistent loop it costs ~100 VGPRs and spills)
-            fft_dif_to_regs(x, logR, twl, tl, tpr, make_src([&](int E) -> float2 { return live ? row[E] : make_float2(0.f, 0.f); }), S[b]);
+            int tl = tid;                         // (opaque copy: keeps the passes' address arithmetic inside the loop)
+            asm volatile("" : "+v"(tl));
+            dif_first_from_regs<LOGR, M0>(x, twl, tl, S[b]);
+            __syncthreads();
+            fft_dif_rest_to_regs<LOGR, LOGR - M0>(x, twl, tl, S[b]);
+            __builtin_amdgcn_sched_barrier(0);    // (the last butterfly is not to be interleaved with the next first pass)
             __syncthreads();                      // the next transform's first pass overwrites x
         }
         for (int q = 0; q < n_pairs; ++q) {
@@ -624,13 +660,14 @@ __global__ __launch_bounds__(kGThreads, 2) void g_rows_fused(const float2* __res
                 }
             int tl = tid;
             asm volatile("" : "+v"(tl));
-            fft_dit_inv_from_regs(x, logR, twl, tl, tpr, v);
+            fft_dit_inv_from_regs<LOGR>(x, twl, tl, v);
             if (live) {
-                float2* row = prod + (((long)wl * n_pairs + q) * n_rows + rib) * R;
+                float2* row = prod + (((long)wl * n_pairs + q) * n_rows + rib0) * R;
+#pragma unroll 4
                 for (int n = tl; n < R; n += tpr) {
                     const float2 w = g_cmul(t1[n & (n1 - 1)], t2[n >> a]);
                     const float2 r = g_cmulc(x[lp(n)], w);
-                    row[n] = make_float2(r.x * scale, r.y * scale);
+                    row[goff + (unsigned)n] = make_float2(r.x * scale, r.y * scale);
                 }
             }
             __syncthreads();                      // x (and, behind the last pair, t1) are rewritten

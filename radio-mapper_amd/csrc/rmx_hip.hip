@@ -1175,6 +1175,7 @@ struct rmx_ctx {
     int g_logL = 0, g_logL1 = 0, g_logL2 = 0, g_lo_bits = 0, g_chunk = 0;
     bool g_fused = false;      // four-step: both row passes in g_rows_fused (n_buoys <= 4, plain batches)
     int g_fused_wgs = 0;       // its persistent grid
+    const void* g_fused_fn = nullptr;
     float2 *g_tw = nullptr, *g_tw1 = nullptr, *g_tw2 = nullptr, *g_thi = nullptr, *g_tlo = nullptr;
     float2 *g_spec = nullptr, *g_spec_r = nullptr, *g_prod = nullptr;   // spectra, de-rotated spectra (CAF), products
     rmx::gen::GTile* g_rec = nullptr;   // per column tile: partial argmax + taps
@@ -1371,6 +1372,12 @@ static size_t gen_rows_lds(int R) {                     // rows + per-row twiddl
     const int a = logR >> 1;
     return ((size_t)(gen::kGThreads / tpr) * ((size_t)gen::lp(R) + (1 << a) + (R >> a)) + (size_t)(R >> 1)) * 8;   // + W_R table
 }
+static const void* fused_fn(int nb, int logR) {         // g_rows_fused<n_buoys, log2 row length>
+#define RMX_FF(NB) (logR == 9 ? (const void*)gen::g_rows_fused<NB, 9> : logR == 10 ? (const void*)gen::g_rows_fused<NB, 10> : \
+                    logR == 11 ? (const void*)gen::g_rows_fused<NB, 11> : (const void*)gen::g_rows_fused<NB, 12>)
+    return nb == 2 ? RMX_FF(2) : nb == 3 ? RMX_FF(3) : RMX_FF(4);
+#undef RMX_FF
+}
 static size_t gen_fused_lds(int R) {                    // g_rows_fused: R/16 threads per row
     int logR = 0;
     while ((1 << logR) < R) ++logR;
@@ -1436,11 +1443,12 @@ static int generic_init(rmx_ctx* c) {
         RMX_HIP(c, hipFuncSetAttribute((const void*)(g_rows<true, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, rows_lds));
         RMX_HIP(c, hipFuncSetAttribute((const void*)(g_rows<false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, rows_lds));
         // both row passes in one kernel when the buoys' spectra rows fit the register file (generic_path.hpp)
-        c->g_fused = c->n_buoys <= 4 && c->g_logL2 >= 5 && c->g_logL2 <= 12;
+        c->g_fused = c->n_buoys <= 4 && c->g_logL2 >= 9 && c->g_logL2 <= 12;
         if (const char* e = getenv("RMX_FUSED")) c->g_fused = c->g_fused && atoi(e) != 0;
         if (c->g_fused) {
             const int flds = (int)gen_fused_lds(1 << c->g_logL2);
-            const void* fn = c->n_buoys == 2 ? (const void*)g_rows_fused<2> : c->n_buoys == 3 ? (const void*)g_rows_fused<3> : (const void*)g_rows_fused<4>;
+            const void* fn = fused_fn(c->n_buoys, c->g_logL2);
+            c->g_fused_fn = fn;
             RMX_HIP(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, flds));
             int per_cu = 0;
             RMX_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kGThreads, (size_t)flds));
@@ -1591,12 +1599,15 @@ static int generic_pairs(rmx_ctx* c, int w0, int wc, int n_pairs, int* d_lag, fl
         const long blocks = (units + upw - 1) / upw;
         const dim3 grid((unsigned)(blocks < c->g_fused_wgs ? blocks : c->g_fused_wgs));
         const float fs = std::ldexp(1.0f, -(logL / 2));
-#define RMX_FUSED(NB)                                                                                                  \
-    hipLaunchKernelGGL((g_rows_fused<NB>), grid, dim3(kGThreads), gen_fused_lds(L2), st, (const float2*)c->g_spec,    \
-                       c->g_prod, c->g_tw2, l2, L1, l1, L, c->g_lo_bits, c->g_thi, c->g_tlo, fs * fs, units, c->g_pairs, \
-                       n_pairs)
-        if (B == 2) RMX_FUSED(2); else if (B == 3) RMX_FUSED(3); else RMX_FUSED(4);
-#undef RMX_FUSED
+        const float2* colsp = c->g_spec;
+        float2* prodp = c->g_prod;
+        const float2 *twp = c->g_tw2, *thip = c->g_thi, *tlop = c->g_tlo;
+        const GPair* pp = c->g_pairs;
+        int a_L1 = L1, a_l1 = l1, a_lo = c->g_lo_bits, a_np = n_pairs;
+        long a_L = L, a_units = units;
+        float a_scale = fs * fs;
+        void* args[] = {&colsp, &prodp, &twp, &a_L1, &a_l1, &a_L, &a_lo, &thip, &tlop, &a_scale, &a_units, &pp, &a_np};
+        RMX_HIP(c, hipLaunchKernel(c->g_fused_fn, grid, dim3(kGThreads), args, gen_fused_lds(L2), st));
     } else
     hipLaunchKernelGGL((g_rows<false, true, true>), rows_grid(c, rows, rpw, rlds, l2), dim3(kGThreads), rlds, st, c->g_prod,
                        c->g_tw2, l2, L1, l1, L, c->g_lo_bits, c->g_thi, c->g_tlo, 1.0f, rows, (const float2*)c->g_spec, spec_j,
