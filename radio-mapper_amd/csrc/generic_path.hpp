@@ -149,7 +149,15 @@ template <class F>
 __device__ __forceinline__ DstFn<F> make_dst(F f) { return DstFn<F>{f}; }
 
 // DIF pass: M stages on blocks of 2^b (forward, W = exp(-2 pi i / R)); no barrier inside
-template <int M, int LOGT, class Src, class Dst>
+// Where a pass takes W_R^(l k 2^(logR-b)) from (TWM): 0 = the half table tw[e], e < R/2, with the sign fix-up;
+// 2 = this pass's own table tw[(k-1) q + l] (consecutive lanes read consecutive entries: the strided reads of
+// mode 0 are 2..16-way LDS bank conflicts -- SQ_LDS_BANK_CONFLICT was half of the LDS cycles of g_rows_fused)
+template <int TWM>
+__device__ __forceinline__ float2 pass_tw(const float2* __restrict__ tw, int es, int l, int k, int q, int half) {
+    if constexpr (TWM == 2) return tw[(k - 1) * q + l];
+    else return tw_full(tw, es * k, half);
+}
+template <int M, int LOGT, int TWM = 0, class Src, class Dst>
 __device__ __forceinline__ void dif_pass(int logR, int b, const float2* __restrict__ tw, int tid, int nthr, const Src& src,
                                          const Dst& dst) {
     constexpr int RAD = 1 << M, T = 1 << LOGT;
@@ -171,7 +179,7 @@ __device__ __forceinline__ void dif_pass(int logR, int b, const float2* __restri
         if (qb > 0) {
             const int es = l << (logR - b);
 #pragma unroll
-            for (int k = 1; k < RAD; ++k) hd.st(brev_m<M>(k) * qs, g_cmul(v[k], tw_full(tw, es * k, half)));
+            for (int k = 1; k < RAD; ++k) hd.st(brev_m<M>(k) * qs, g_cmul(v[k], pass_tw<TWM>(tw, es, l, k, q, half)));
         } else {
 #pragma unroll
             for (int k = 1; k < RAD; ++k) hd.st(brev_m<M>(k) * qs, v[k]);
@@ -179,7 +187,7 @@ __device__ __forceinline__ void dif_pass(int logR, int b, const float2* __restri
     }
 }
 // DIT pass with conjugated twiddles: the exact inverse data flow (unnormalised); no barrier inside
-template <int M, int LOGT, class Src, class Dst>
+template <int M, int LOGT, int TWM = 0, class Src, class Dst>
 __device__ __forceinline__ void dit_pass(int logR, int b, const float2* __restrict__ tw, int tid, int nthr, const Src& src,
                                          const Dst& dst) {
     constexpr int RAD = 1 << M, T = 1 << LOGT;
@@ -202,7 +210,7 @@ __device__ __forceinline__ void dit_pass(int logR, int b, const float2* __restri
             const int es = l << (logR - b);
 #pragma unroll
             for (int k = 1; k < RAD; ++k) {
-                const float2 e = g_cmulc(hs.ld(brev_m<M>(k) * qs), tw_full(tw, es * k, half));
+                const float2 e = g_cmulc(hs.ld(brev_m<M>(k) * qs), pass_tw<TWM>(tw, es, l, k, q, half));
                 v[k] = make_float2(e.y, e.x);
             }
         } else {
@@ -526,12 +534,38 @@ __global__ __launch_bounds__(kGThreads) void g_rows(float2* __restrict__ data, c
 __host__ __device__ constexpr int fused_pass_m(int left) {
     return (left & 3) == 0 ? 4 : ((left & 3) == 1 && left > 1 ? 3 : (left & 3));
 }
+// Twiddles: every pass (block size 2^B, M stages) has its own table [k = 1 .. 2^M - 1][l < 2^(B-M)] =
+// W_R^(l k 2^(LOGR-B)) in LDS, one behind the other from the first pass (B = LOGR) down; the inverse's passes are
+// the forward's in reverse order and use the same tables conjugated.  Lanes read consecutive entries (the
+// strided reads of a shared W_R table were 2..16-way bank conflicts: half of this kernel's LDS cycles).
+__host__ __device__ constexpr int fused_tab_off(int logR, int B) {      // offset of pass B's table, in entries
+    int cur = logR, acc = 0;
+    while (cur > B) {
+        const int M = fused_pass_m(cur - 4);
+        acc += ((1 << M) - 1) << (cur - M);
+        cur -= M;
+    }
+    return acc;
+}
+__host__ __device__ constexpr int fused_tab_total(int logR) { return fused_tab_off(logR, 4); }
+template <int LOGR, int B>
+__device__ __forceinline__ void fused_tab_build(float2* tab, const float2* __restrict__ tw) {
+    if constexpr (B > 4) {
+        constexpr int M = fused_pass_m(B - 4), q = 1 << (B - M), n = ((1 << M) - 1) * q;
+        float2* t = tab + fused_tab_off(LOGR, B);
+        for (int e = threadIdx.x; e < n; e += kGThreads) {
+            const int k = e / q + 1, l = e % q;
+            t[e] = tw_full(tw, (l << (LOGR - B)) * k, 1 << (LOGR - 1));
+        }
+        fused_tab_build<LOGR, B - M>(tab, tw);
+    }
+}
 // The thread's 16 raw inputs of a row's FIRST pass (radix 2^M on the whole row: butterfly idx = tid + it * nthr takes
 // the elements idx + m * R / 2^M) sit in registers, raw[it * 2^M + m], loaded by the caller -- all rows of a unit at
 // once, one HBM latency per unit instead of one per row, in the registers that later hold the spectra.
 template <int LOGR, int M>
-__device__ __forceinline__ void dif_first_from_regs(float2* x, const float2* __restrict__ tw, int tid, const float2 (&raw)[16]) {
-    constexpr int RAD = 1 << M, NIT = 16 / RAD, q = 1 << (LOGR - M), half = 1 << (LOGR - 1), nthr = 1 << (LOGR - 4);
+__device__ __forceinline__ void dif_first_from_regs(float2* x, const float2* __restrict__ tab, int tid, const float2 (&raw)[16]) {
+    constexpr int RAD = 1 << M, NIT = 16 / RAD, q = 1 << (LOGR - M), nthr = 1 << (LOGR - 4);
     const LdsIO mid{x};
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -543,18 +577,18 @@ __device__ __forceinline__ void dif_first_from_regs(float2* x, const float2* __r
         dft_reg<RAD>(v);
         hd.st(0, v[0]);
 #pragma unroll
-        for (int k = 1; k < RAD; ++k) hd.st(brev_m<M>(k) * q, g_cmul(v[k], tw_full(tw, idx * k, half)));
+        for (int k = 1; k < RAD; ++k) hd.st(brev_m<M>(k) * q, g_cmul(v[k], tab[(k - 1) * q + idx]));
     }
 }
 // passes from blocks of 2^B down to the 16-point blocks, whose butterfly ends in registers
 template <int LOGR, int B>
-__device__ __forceinline__ void fft_dif_rest_to_regs(float2* x, const float2* __restrict__ tw, int tid, float2 (&out)[16]) {
+__device__ __forceinline__ void fft_dif_rest_to_regs(float2* x, const float2* __restrict__ tab, int tid, float2 (&out)[16]) {
     const LdsIO mid{x};
     if constexpr (B > 4) {
         constexpr int M = fused_pass_m(B - 4);
-        dif_pass<M, 0>(LOGR, B, tw, tid, 1 << (LOGR - 4), mid, mid);
+        dif_pass<M, 0, 2>(LOGR, B, tab + fused_tab_off(LOGR, B), tid, 1 << (LOGR - 4), mid, mid);
         __syncthreads();
-        fft_dif_rest_to_regs<LOGR, B - M>(x, tw, tid, out);
+        fft_dif_rest_to_regs<LOGR, B - M>(x, tab, tid, out);
     } else {
         const auto h = mid.open(tid << 4);
 #pragma unroll
@@ -562,19 +596,21 @@ __device__ __forceinline__ void fft_dif_rest_to_regs(float2* x, const float2* __
         dft16(out);     // out[k] belongs at position 16 tid + bitrev4(k): the inverse's first pass reads it as its input k
     }
 }
+// the forward's passes B, B - M, ... in reverse order (the passes below B first); a barrier in front of each
 template <int LOGR, int B>
-__device__ __forceinline__ void fft_dit_rest(float2* x, const float2* __restrict__ tw, int tid) {
-    if constexpr (B < LOGR) {
+__device__ __forceinline__ void fft_dit_up(float2* x, const float2* __restrict__ tab, int tid) {
+    if constexpr (B > 4) {
+        constexpr int M = fused_pass_m(B - 4);
+        fft_dit_up<LOGR, B - M>(x, tab, tid);
         const LdsIO mid{x};
-        constexpr int M = fused_pass_m(LOGR - B);
-        dit_pass<M, 0>(LOGR, B + M, tw, tid, 1 << (LOGR - 4), mid, mid);
         __syncthreads();
-        fft_dit_rest<LOGR, B + M>(x, tw, tid);
+        dit_pass<M, 0, 2>(LOGR, B, tab + fused_tab_off(LOGR, B), tid, 1 << (LOGR - 4), mid, mid);
     }
 }
-// v[k]: the (unswapped) input k of the thread's first DIT butterfly; result in LDS (natural order)
+// v[k]: the (unswapped) input k of the thread's first DIT butterfly; result in LDS (natural order), no barrier
+// behind the last pass
 template <int LOGR>
-__device__ __forceinline__ void fft_dit_inv_from_regs(float2* x, const float2* __restrict__ tw, int tid, float2 (&v)[16]) {
+__device__ __forceinline__ void fft_dit_inv_from_regs(float2* x, const float2* __restrict__ tab, int tid, float2 (&v)[16]) {
     const LdsIO mid{x};
 #pragma unroll
     for (int k = 0; k < 16; ++k) v[k] = make_float2(v[k].y, v[k].x);
@@ -582,8 +618,7 @@ __device__ __forceinline__ void fft_dit_inv_from_regs(float2* x, const float2* _
     const auto h = mid.open(tid << 4);
 #pragma unroll
     for (int m = 0; m < 16; ++m) h.st(m, make_float2(v[m].y, v[m].x));
-    __syncthreads();
-    fft_dit_rest<LOGR, 4>(x, tw, tid);
+    fft_dit_up<LOGR, LOGR>(x, tab, tid);
 }
 template <int NB>
 __device__ __forceinline__ void constexpr_pair(int ij, const float2 (&S)[NB][16], float2 (&v)[16]) {
@@ -606,7 +641,7 @@ __global__ __launch_bounds__(kGThreads, 2) void g_rows_fused(const float2* __res
     float2* t1 = reinterpret_cast<float2*>(gsm) + upw * (int)lp(R) + g * (n1 + n2);
     float2* t2 = t1 + n1;
     float2* twl = reinterpret_cast<float2*>(gsm) + upw * ((int)lp(R) + n1 + n2);
-    for (int k = threadIdx.x; k < (R >> 1); k += kGThreads) twl[k] = tw[k];
+    fused_tab_build<LOGR, LOGR>(twl, tw);
     const long n_blocks = (n_units + upw - 1) / upw;
     __syncthreads();
     for (long blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
@@ -661,6 +696,7 @@ __global__ __launch_bounds__(kGThreads, 2) void g_rows_fused(const float2* __res
             int tl = tid;
             asm volatile("" : "+v"(tl));
             fft_dit_inv_from_regs<LOGR>(x, twl, tl, v);
+            __syncthreads();
             if (live) {
                 float2* row = prod + (((long)wl * n_pairs + q) * n_rows + rib0) * R;
 #pragma unroll 4
