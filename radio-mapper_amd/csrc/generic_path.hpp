@@ -28,6 +28,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <type_traits>
 #include <vector>
 
 namespace rmx {
@@ -113,6 +114,7 @@ __device__ __forceinline__ float2 tw_full(const float2* __restrict__ tw, int e, 
 // E0 = (j << LOGT) | c, its m-th element sits o = m * (q << LOGT) further on.
 struct LdsIO {      // the transform buffer in LDS, padded by lp()
     float2* x;
+    static __host__ __device__ constexpr int pos(int e) { return e + (e >> 4); }
     struct H {
         float2* p;
         // lp(E0 + o) = lp(E0) + o + (o >> 4): E0's 16-block has fewer than the stride's worth of elements in front
@@ -121,6 +123,25 @@ struct LdsIO {      // the transform buffer in LDS, padded by lp()
         __device__ __forceinline__ void st(int o, float2 v) const { p[o + (o >> 4)] = v; }
     };
     __device__ __forceinline__ H open(int E0) const { return H{x + (E0 + (E0 >> 4))}; }
+};
+// Second layout of the same buffer: 16 complex of padding per 2^BM elements, e -> e + 16 (e >> BM).  lp() keeps a
+// thread's 16 neighbours (and lanes 16 elements apart) on distinct banks but puts 32 CONSECUTIVE elements on 34
+// slots (lanes 0 and 31 collide: every unit-stride access a 2-way conflict); this one keeps unit-stride accesses
+// and the 16-lanes-here, 16-lanes-2^BM-further pattern of a q = 16 pass conflict free.  g_rows_fused alternates:
+// passes whose lanes walk consecutive elements use this layout, the 16-neighbour butterflies lp().  A pass that
+// reads one layout and writes the other is only safe when a butterfly's elements occupy the same REGION in both
+// (its lanes sit in one wave, whose reads precede its writes): blocks of 2^BM elements must start at the same
+// position in both layouts, which holds for BM = 8 (272 h) and not for BM = 6 (80 h against 68 h).
+template <int BM>
+struct LdsIOA {
+    float2* x;
+    static __host__ __device__ constexpr int pos(int e) { return e + ((e >> BM) << 4); }
+    struct H {
+        float2* p;
+        __device__ __forceinline__ float2 ld(int o) const { return p[o + ((o >> BM) << 4)]; }     // o: below 2^BM or a multiple of it
+        __device__ __forceinline__ void st(int o, float2 v) const { p[o + ((o >> BM) << 4)] = v; }
+    };
+    __device__ __forceinline__ H open(int E0) const { return H{x + (E0 + ((E0 >> BM) << 4))}; }
 };
 // adaptors: a pass end given as a callable on the element index (source) or on (E0, o, value) (sink)
 template <class F>
@@ -563,14 +584,25 @@ __device__ __forceinline__ void fused_tab_build(float2* tab, const float2* __res
 // The thread's 16 raw inputs of a row's FIRST pass (radix 2^M on the whole row: butterfly idx = tid + it * nthr takes
 // the elements idx + m * R / 2^M) sit in registers, raw[it * 2^M + m], loaded by the caller -- all rows of a unit at
 // once, one HBM latency per unit instead of one per row, in the registers that later hold the spectra.
-template <int LOGR, int M>
+// LDS layouts (LdsIOA above): the first forward pass writes, the one middle pass (q = 16, blocks of 2^BM) reads
+// layout A; the middle pass writes and the 16-neighbour butterfly reads lp(); the inverse the other way round.
+template <int LOGR>
+struct FusedPlan {
+    static constexpr int M0 = fused_pass_m(LOGR - 4), BM = LOGR - M0, MM = BM - 4;      // first pass, middle pass
+    static_assert(MM >= 1 && MM <= 4 && fused_pass_m(BM - 4) == MM, "rows of 2^9 .. 2^12: first pass, one middle pass, 16-point blocks");
+    // the unit-stride layout where its blocks line up with lp()'s (LdsIOA); rows of 512 keep lp() throughout
+    using IOA = std::conditional_t<BM == 8, LdsIOA<8>, LdsIO>;
+    static constexpr int buf = LdsIO::pos(1 << LOGR) > IOA::pos(1 << LOGR) ? LdsIO::pos(1 << LOGR) : IOA::pos(1 << LOGR);
+};
+template <int LOGR>
 __device__ __forceinline__ void dif_first_from_regs(float2* x, const float2* __restrict__ tab, int tid, const float2 (&raw)[16]) {
-    constexpr int RAD = 1 << M, NIT = 16 / RAD, q = 1 << (LOGR - M), nthr = 1 << (LOGR - 4);
-    const LdsIO mid{x};
+    using P = FusedPlan<LOGR>;
+    constexpr int M = P::M0, RAD = 1 << M, NIT = 16 / RAD, q = 1 << (LOGR - M), nthr = 1 << (LOGR - 4);
+    const typename P::IOA io{x};
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int idx = tid + it * nthr;
-        const auto hd = mid.open(idx);
+        const auto hd = io.open(idx);
         float2 v[RAD];
 #pragma unroll
         for (int m = 0; m < RAD; ++m) v[m] = raw[it * RAD + m];
@@ -580,45 +612,35 @@ __device__ __forceinline__ void dif_first_from_regs(float2* x, const float2* __r
         for (int k = 1; k < RAD; ++k) hd.st(brev_m<M>(k) * q, g_cmul(v[k], tab[(k - 1) * q + idx]));
     }
 }
-// passes from blocks of 2^B down to the 16-point blocks, whose butterfly ends in registers
-template <int LOGR, int B>
+// the middle pass and the 16-point blocks, whose butterfly ends in registers
+template <int LOGR>
 __device__ __forceinline__ void fft_dif_rest_to_regs(float2* x, const float2* __restrict__ tab, int tid, float2 (&out)[16]) {
-    const LdsIO mid{x};
-    if constexpr (B > 4) {
-        constexpr int M = fused_pass_m(B - 4);
-        dif_pass<M, 0, 2>(LOGR, B, tab + fused_tab_off(LOGR, B), tid, 1 << (LOGR - 4), mid, mid);
-        __syncthreads();
-        fft_dif_rest_to_regs<LOGR, B - M>(x, tab, tid, out);
-    } else {
-        const auto h = mid.open(tid << 4);
+    using P = FusedPlan<LOGR>;
+    const LdsIO nb{x};
+    dif_pass<P::MM, 0, 2>(LOGR, P::BM, tab + fused_tab_off(LOGR, P::BM), tid, 1 << (LOGR - 4), typename P::IOA{x}, nb);
+    __syncthreads();
+    const auto h = nb.open(tid << 4);
 #pragma unroll
-        for (int m = 0; m < 16; ++m) out[m] = h.ld(m);
-        dft16(out);     // out[k] belongs at position 16 tid + bitrev4(k): the inverse's first pass reads it as its input k
-    }
+    for (int m = 0; m < 16; ++m) out[m] = h.ld(m);
+    dft16(out);         // out[k] belongs at position 16 tid + bitrev4(k): the inverse's first pass reads it as its input k
 }
-// the forward's passes B, B - M, ... in reverse order (the passes below B first); a barrier in front of each
-template <int LOGR, int B>
-__device__ __forceinline__ void fft_dit_up(float2* x, const float2* __restrict__ tab, int tid) {
-    if constexpr (B > 4) {
-        constexpr int M = fused_pass_m(B - 4);
-        fft_dit_up<LOGR, B - M>(x, tab, tid);
-        const LdsIO mid{x};
-        __syncthreads();
-        dit_pass<M, 0, 2>(LOGR, B, tab + fused_tab_off(LOGR, B), tid, 1 << (LOGR - 4), mid, mid);
-    }
-}
-// v[k]: the (unswapped) input k of the thread's first DIT butterfly; result in LDS (natural order), no barrier
-// behind the last pass
+// v[k]: the (unswapped) input k of the thread's first DIT butterfly; result in LDS (natural order, layout A), no
+// barrier behind the last pass
 template <int LOGR>
 __device__ __forceinline__ void fft_dit_inv_from_regs(float2* x, const float2* __restrict__ tab, int tid, float2 (&v)[16]) {
-    const LdsIO mid{x};
+    using P = FusedPlan<LOGR>;
+    const LdsIO nb{x};
+    const typename P::IOA io{x};
 #pragma unroll
     for (int k = 0; k < 16; ++k) v[k] = make_float2(v[k].y, v[k].x);
     dft16(v);
-    const auto h = mid.open(tid << 4);
+    const auto h = nb.open(tid << 4);
 #pragma unroll
     for (int m = 0; m < 16; ++m) h.st(m, make_float2(v[m].y, v[m].x));
-    fft_dit_up<LOGR, LOGR>(x, tab, tid);
+    __syncthreads();
+    dit_pass<P::MM, 0, 2>(LOGR, P::BM, tab + fused_tab_off(LOGR, P::BM), tid, 1 << (LOGR - 4), nb, io);
+    __syncthreads();
+    dit_pass<P::M0, 0, 2>(LOGR, LOGR, tab, tid, 1 << (LOGR - 4), io, io);
 }
 template <int NB>
 __device__ __forceinline__ void constexpr_pair(int ij, const float2 (&S)[NB][16], float2 (&v)[16]) {
@@ -634,13 +656,14 @@ __global__ __launch_bounds__(kGThreads, 2) void g_rows_fused(const float2* __res
                                                           const GPair* __restrict__ pairs, int n_pairs) {
     extern __shared__ __attribute__((aligned(16))) char gsm[];
     constexpr int R = 1 << LOGR, tpr = R >> 4, upw = kGThreads / tpr;   // threads per row, (window, rib) units per workgroup
-    constexpr int M0 = fused_pass_m(LOGR - 4);                          // stages of the forward rows' first pass
+    using P = FusedPlan<LOGR>;
+    constexpr int M0 = P::M0;                                           // stages of the forward rows' first pass
     constexpr int a = LOGR >> 1, n1 = 1 << a, n2 = R >> a;
     const int g = threadIdx.x / tpr, tid = threadIdx.x % tpr;
-    float2* x = reinterpret_cast<float2*>(gsm) + g * (int)lp(R);
-    float2* t1 = reinterpret_cast<float2*>(gsm) + upw * (int)lp(R) + g * (n1 + n2);
+    float2* x = reinterpret_cast<float2*>(gsm) + g * P::buf;
+    float2* t1 = reinterpret_cast<float2*>(gsm) + upw * P::buf + g * (n1 + n2);
     float2* t2 = t1 + n1;
-    float2* twl = reinterpret_cast<float2*>(gsm) + upw * ((int)lp(R) + n1 + n2);
+    float2* twl = reinterpret_cast<float2*>(gsm) + upw * (P::buf + n1 + n2);
     fused_tab_build<LOGR, LOGR>(twl, tw);
     const long n_blocks = (n_units + upw - 1) / upw;
     __syncthreads();
@@ -674,9 +697,9 @@ __global__ __launch_bounds__(kGThreads, 2) void g_rows_fused(const float2* __res
         for (int b = 0; b < NB; ++b) {
             int tl = tid;                         // (opaque copy: keeps the passes' address arithmetic inside the loop)
             asm volatile("" : "+v"(tl));
-            dif_first_from_regs<LOGR, M0>(x, twl, tl, S[b]);
+            dif_first_from_regs<LOGR>(x, twl, tl, S[b]);
             __syncthreads();
-            fft_dif_rest_to_regs<LOGR, LOGR - M0>(x, twl, tl, S[b]);
+            fft_dif_rest_to_regs<LOGR>(x, twl, tl, S[b]);
             __builtin_amdgcn_sched_barrier(0);    // (the last butterfly is not to be interleaved with the next first pass)
             __syncthreads();                      // the next transform's first pass overwrites x
         }
@@ -702,7 +725,7 @@ __global__ __launch_bounds__(kGThreads, 2) void g_rows_fused(const float2* __res
 #pragma unroll 4
                 for (int n = tl; n < R; n += tpr) {
                     const float2 w = g_cmul(t1[n & (n1 - 1)], t2[n >> a]);
-                    const float2 r = g_cmulc(x[lp(n)], w);
+                    const float2 r = g_cmulc(x[P::IOA::pos(n)], w);
                     row[goff + (unsigned)n] = make_float2(r.x * scale, r.y * scale);
                 }
             }

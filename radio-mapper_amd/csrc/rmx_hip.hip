@@ -1382,7 +1382,8 @@ static size_t gen_fused_lds(int R) {                    // g_rows_fused: R/16 th
     int logR = 0;
     while ((1 << logR) < R) ++logR;
     const int a = logR >> 1, tpr = R >> 4, upw = gen::kGThreads / (tpr > 0 ? tpr : 1);
-    return ((size_t)upw * ((size_t)gen::lp(R) + (1 << a) + (R >> a)) + (size_t)gen::fused_tab_total(logR)) * 8;   // + the passes' twiddle tables
+    const int buf = logR == 9 ? gen::FusedPlan<9>::buf : logR == 10 ? gen::FusedPlan<10>::buf : logR == 11 ? gen::FusedPlan<11>::buf : gen::FusedPlan<12>::buf;
+    return ((size_t)upw * ((size_t)buf + (1 << a) + (R >> a)) + (size_t)gen::fused_tab_total(logR)) * 8;   // + the passes' twiddle tables
 }
 static size_t gen_cols_lds(int l1) {                    // [L1][T] tile + T per-column twiddle tables
     const int a = l1 >> 1, T = 1 << gen::col_log_t(l1);
