@@ -124,6 +124,22 @@ struct LdsIO {      // the transform buffer in LDS, padded by lp()
     };
     __device__ __forceinline__ H open(int E0) const { return H{x + (E0 + (E0 >> 4))}; }
 };
+// Tiles of 2^LOGT interleaved columns (LOGT > 0) are NOT padded: a half-wave (16 columns x 2 rows, or 8 x 4) walks
+// 32 consecutive complex numbers in every pass whose lanes take neighbouring rows -- conflict free -- and lp()'s
+// extra element per 16 made each of those accesses, and every tile load / store loop, a 2-way conflict (62 % of the
+// LDS cycles of g_cols_fwd were conflict cycles).  Only the last pass (lanes 2^M rows apart) stays 2-way.
+struct LdsFlat {
+    float2* x;
+    static __host__ __device__ constexpr int pos(int e) { return e; }
+    struct H {
+        float2* p;
+        __device__ __forceinline__ float2 ld(int o) const { return p[o]; }
+        __device__ __forceinline__ void st(int o, float2 v) const { p[o] = v; }
+    };
+    __device__ __forceinline__ H open(int E0) const { return H{x + E0}; }
+};
+template <int LOGT>
+using LdsIOFor = std::conditional_t<LOGT == 0, LdsIO, LdsFlat>;
 // Second layout of the same buffer: 16 complex of padding per 2^BM elements, e -> e + 16 (e >> BM).  lp() keeps a
 // thread's 16 neighbours (and lanes 16 elements apart) on distinct banks but puts 32 CONSECUTIVE elements on 34
 // slots (lanes 0 and 31 collide: every unit-stride access a 2-way conflict); this one keeps unit-stride accesses
@@ -272,7 +288,7 @@ __device__ __forceinline__ void dit_pass_m(int M, int logR, int b, const float2*
 template <int LOGT, class First, class Last>
 __device__ __forceinline__ void fft_dif(float2* x, int logR, const float2* __restrict__ tw, int tid, int nthr,
                                         const First& first, const Last& last) {
-    const LdsIO mid{x};
+    const LdsIOFor<LOGT> mid{x};
     int b = logR;
     if (b <= 4) {
         dif_pass_m<LOGT>(b, logR, b, tw, tid, nthr, first, last);
@@ -290,7 +306,7 @@ __device__ __forceinline__ void fft_dif(float2* x, int logR, const float2* __res
 template <int LOGT, class First, class Last>
 __device__ __forceinline__ void fft_dit_inv(float2* x, int logR, const float2* __restrict__ tw, int tid, int nthr,
                                             const First& first, const Last& last) {
-    const LdsIO mid{x};
+    const LdsIOFor<LOGT> mid{x};
     if (logR <= 4) {
         dit_pass_m<LOGT>(logR, logR, logR, tw, tid, nthr, first, last);
         return;
@@ -308,13 +324,13 @@ __device__ __forceinline__ void fft_dit_inv(float2* x, int logR, const float2* _
 // in place in LDS, barrier behind the last pass too
 template <int LOGT = 0>
 __device__ __forceinline__ void lds_dif(float2* x, int logR, const float2* __restrict__ tw, int tid, int nthr) {
-    const LdsIO io{x};
+    const LdsIOFor<LOGT> io{x};
     fft_dif<LOGT>(x, logR, tw, tid, nthr, io, io);
     __syncthreads();
 }
 template <int LOGT = 0>
 __device__ __forceinline__ void lds_dit_inv(float2* x, int logR, const float2* __restrict__ tw, int tid, int nthr) {
-    const LdsIO io{x};
+    const LdsIOFor<LOGT> io{x};
     fft_dit_inv<LOGT>(x, logR, tw, tid, nthr, io, io);
     __syncthreads();
 }
@@ -759,19 +775,20 @@ __global__ __launch_bounds__(1024) void g_cols_fwd(const void* __restrict__ iq, 
     const long item = first_item + blockIdx.y;
     // per-column twiddle tables W_L^(n2*e) = T1[e & (2^a-1)] * T2[e >> a] (n2*e < L: no reduction) and the W_L1 table
     const int a = l1 >> 1, na = 1 << a, nb = L1 >> a;
-    float2* tab = x + lp((long)L1 << kColLogT);             // [T][na + nb]
-    float2* twl = tab + (long)kColT * (na + nb);
+    float2* tab = x + ((long)L1 << kColLogT);                 // [T][na + nb + 1]: an odd stride, or the 16 columns' reads of one
+    constexpr int kTabPad = 1;                                //   entry sit on two banks (8-way conflict)
+    float2* twl = tab + (long)kColT * (na + nb + kTabPad);
     for (int k = tid; k < (L1 >> 1); k += nthr) twl[k] = tw[k];
     for (int idx = tid; idx < kColT * (na + nb); idx += nthr) {
         const int c = idx / (na + nb), e = idx % (na + nb);
         const long ee = e < na ? (long)e : ((long)(e - na) << a);
-        tab[idx] = big_tw((long)(c0 + c) * ee, lo_bits, thi, tlo);
+        tab[c * (na + nb + kTabPad) + e] = big_tw((long)(c0 + c) * ee, lo_bits, thi, tlo);
     }
     __syncthreads();
     // (first pass from HBM / last pass to HBM measured slower here: 2.0 vs 1.58 ms on cfg2 -- the sink's table
     // lookups on top of a radix-16 pass spill)
     const int nz = (L1 >> 1) << kColLogT;                     // only the rows n1 < L1/2 are non-zero
-    for (int idx = nz + tid; idx < (L1 << kColLogT); idx += nthr) x[lp(idx)] = make_float2(0.f, 0.f);
+    for (int idx = nz + tid; idx < (L1 << kColLogT); idx += nthr) x[idx] = make_float2(0.f, 0.f);
     batched<8>(tid, nz, nthr,
                [&](int idx) -> float2 {
                    const long n = (long)(idx >> kColLogT) * L2 + c0 + (idx & (kColT - 1));
@@ -784,15 +801,15 @@ __global__ __launch_bounds__(1024) void g_cols_fwd(const void* __restrict__ iq, 
                    }
                    return rot ? rot_mul(v, rot[n]) : v;
                },
-               [&](int idx, float2 v) { x[lp(idx)] = v; });
+               [&](int idx, float2 v) { x[idx] = v; });
     __syncthreads();
     lds_dif<kColLogT>(x, l1, twl, tid, nthr);
     float2* o = out + (long)blockIdx.y * L;
-    batched<8>(tid, L1 << kColLogT, nthr, [&](int idx) -> float2 { return x[lp(idx)]; },
+    batched<8>(tid, L1 << kColLogT, nthr, [&](int idx) -> float2 { return x[idx]; },
                [&](int idx, float2 v) {
                    const int c = idx & (kColT - 1), pos = idx >> kColLogT;
                    const int k1 = brev(pos, l1);
-                   const float2* tc = tab + c * (na + nb);
+                   const float2* tc = tab + c * (na + nb + kTabPad);
                    const float2 w = g_cmul(tc[k1 & (na - 1)], tc[na + (k1 >> a)]);
                    o[(long)pos * L2 + c0 + c] = g_cmul(v, w);
                });
@@ -816,8 +833,8 @@ __global__ __launch_bounds__(1024) void g_cols_inv(const float2* __restrict__ in
     const long L = (long)L1 << l2;
     const int N = (int)(L >> 1);
     const int c0 = blockIdx.x * kColT;
-    float2* twl = x + lp((long)L1 << kColLogT) + (long)kColT * ((1 << (l1 >> 1)) + (L1 >> (l1 >> 1)));
-    float* sv = reinterpret_cast<float*>(x + lp((long)L1 << kColLogT));   // 16 + 16 words in the (unused here) table region
+    float2* twl = x + ((long)L1 << kColLogT) + (long)kColT * ((1 << (l1 >> 1)) + (L1 >> (l1 >> 1)) + 1);
+    float* sv = reinterpret_cast<float*>(x + ((long)L1 << kColLogT));   // 16 + 16 words in the (unused here) table region
     int* sk = reinterpret_cast<int*>(sv + 16);
     for (int k = tid; k < (L1 >> 1); k += nthr) twl[k] = tw[k];
     const float2* src = in + (long)blockIdx.y * L;
@@ -836,14 +853,14 @@ __global__ __launch_bounds__(1024) void g_cols_inv(const float2* __restrict__ in
             const int k = full_index((int)m, N);
             const float v = e.x * e.x + e.y * e.y;
             if (k >= 0 && (v > best || (v == best && k < bk))) { best = v; bk = k; }
-            x[E0 + (E0 >> 4) + off + (off >> 4)] = make_float2(v, 0.0f);
+            x[E0 + off] = make_float2(v, 0.0f);
         }));
     __syncthreads();
     // halo: |r|^2 of columns c0 and c0 + T - 1, all rows: [slot][tile][2][L1]
     float* hb = halo + ((long)blockIdx.y * gridDim.x + blockIdx.x) * 2L * L1;
     for (int n1 = tid; n1 < 2 * L1; n1 += nthr) {
         const int row = n1 & (L1 - 1), col = n1 < L1 ? 0 : kColT - 1;
-        hb[n1] = x[lp((row << kColLogT) + col)].x;
+        hb[n1] = x[(row << kColLogT) + col].x;
     }
     block_argmax_w(best, bk, sv, sk, tid, nthr);
     if (tid == 0) {
@@ -856,8 +873,8 @@ __global__ __launch_bounds__(1024) void g_cols_inv(const float2* __restrict__ in
             const int c = (int)(m & (L2 - 1)) - c0, row = (int)(m >> l2);
             // 'full' neighbours are the circular neighbours m -+ 1 (the excluded lag -N sits between the two
             // ends of the 'full' range): inside this tile when the column is
-            if (c > 0) t.tm = x[lp((row << kColLogT) + c - 1)].x;
-            if (c < kColT - 1) t.tp = x[lp((row << kColLogT) + c + 1)].x;
+            if (c > 0) t.tm = x[(row << kColLogT) + c - 1].x;
+            if (c < kColT - 1) t.tp = x[(row << kColLogT) + c + 1].x;
         }
         rec[(long)blockIdx.y * gridDim.x + blockIdx.x] = t;
     }
