@@ -138,8 +138,16 @@ struct LdsFlat {
     };
     __device__ __forceinline__ H open(int E0) const { return H{x + E0}; }
 };
-template <int LOGT>
-using LdsIOFor = std::conditional_t<LOGT == 0, LdsIO, LdsFlat>;
+#ifndef RMX_TILE_FLAT_FWD
+#define RMX_TILE_FLAT_FWD 1
+#endif
+#ifndef RMX_TILE_FLAT_INV
+#define RMX_TILE_FLAT_INV 0
+#endif
+template <int LOGT, bool FLAT>
+using LdsIOFor = std::conditional_t<LOGT == 0 || !FLAT, LdsIO, LdsFlat>;
+using TileFwd = LdsIOFor<4, RMX_TILE_FLAT_FWD != 0>;      // tile layout of g_cols_fwd / g_cols_inv
+using TileInv = LdsIOFor<4, RMX_TILE_FLAT_INV != 0>;
 // Second layout of the same buffer: 16 complex of padding per 2^BM elements, e -> e + 16 (e >> BM).  lp() keeps a
 // thread's 16 neighbours (and lanes 16 elements apart) on distinct banks but puts 32 CONSECUTIVE elements on 34
 // slots (lanes 0 and 31 collide: every unit-stride access a 2-way conflict); this one keeps unit-stride accesses
@@ -288,7 +296,7 @@ __device__ __forceinline__ void dit_pass_m(int M, int logR, int b, const float2*
 template <int LOGT, class First, class Last>
 __device__ __forceinline__ void fft_dif(float2* x, int logR, const float2* __restrict__ tw, int tid, int nthr,
                                         const First& first, const Last& last) {
-    const LdsIOFor<LOGT> mid{x};
+    const LdsIOFor<LOGT, RMX_TILE_FLAT_FWD != 0> mid{x};
     int b = logR;
     if (b <= 4) {
         dif_pass_m<LOGT>(b, logR, b, tw, tid, nthr, first, last);
@@ -306,7 +314,7 @@ __device__ __forceinline__ void fft_dif(float2* x, int logR, const float2* __res
 template <int LOGT, class First, class Last>
 __device__ __forceinline__ void fft_dit_inv(float2* x, int logR, const float2* __restrict__ tw, int tid, int nthr,
                                             const First& first, const Last& last) {
-    const LdsIOFor<LOGT> mid{x};
+    const LdsIOFor<LOGT, RMX_TILE_FLAT_INV != 0> mid{x};
     if (logR <= 4) {
         dit_pass_m<LOGT>(logR, logR, logR, tw, tid, nthr, first, last);
         return;
@@ -324,13 +332,13 @@ __device__ __forceinline__ void fft_dit_inv(float2* x, int logR, const float2* _
 // in place in LDS, barrier behind the last pass too
 template <int LOGT = 0>
 __device__ __forceinline__ void lds_dif(float2* x, int logR, const float2* __restrict__ tw, int tid, int nthr) {
-    const LdsIOFor<LOGT> io{x};
+    const LdsIOFor<LOGT, RMX_TILE_FLAT_FWD != 0> io{x};
     fft_dif<LOGT>(x, logR, tw, tid, nthr, io, io);
     __syncthreads();
 }
 template <int LOGT = 0>
 __device__ __forceinline__ void lds_dit_inv(float2* x, int logR, const float2* __restrict__ tw, int tid, int nthr) {
-    const LdsIOFor<LOGT> io{x};
+    const LdsIOFor<LOGT, RMX_TILE_FLAT_INV != 0> io{x};
     fft_dit_inv<LOGT>(x, logR, tw, tid, nthr, io, io);
     __syncthreads();
 }
@@ -760,6 +768,17 @@ __global__ __launch_bounds__(kGThreads, 2) void g_rows_fused(const float2* __res
 __host__ __device__ constexpr int col_log_t(int l1) { return l1 >= 10 ? 3 : 4; }
 // forward: zero-padded window -> out[k1'][n2] = W_L^(n2*k1) * sum_n1 x[n1][n2] W_L1^(n1*k1)
 //   (k1' = bit-reversed k1).  grid (L2/T, items); only the rows n1 < L1/2 are non-zero and read.
+// Workgroup -> tile: the dispatcher deals consecutive workgroups round-robin to the 8 XCDs, so with tile =
+// blockIdx.x the 128-byte row segments of neighbouring tiles -- one DRAM page -- are fetched through 8 different L2s
+// at unrelated times.  Remapped, XCD k walks the tiles [k n/8, (k+1) n/8): its 64 resident workgroups read runs of
+// adjacent segments of the same rows together.
+__device__ __forceinline__ int xcd_tile(int bid, int n) {
+#ifdef RMX_NO_XCD_REMAP
+    return bid;
+#else
+    return (n & 7) == 0 ? (bid & 7) * (n >> 3) + (bid >> 3) : bid;
+#endif
+}
 template <bool U8, int kColLogT>
 __global__ __launch_bounds__(1024) void g_cols_fwd(const void* __restrict__ iq, float2* __restrict__ out,
                                                    const float2* __restrict__ tw, int l1, int l2, long first_item,
@@ -771,11 +790,11 @@ __global__ __launch_bounds__(1024) void g_cols_fwd(const void* __restrict__ iq, 
     float2* x = reinterpret_cast<float2*>(gsm);
     const int L1 = 1 << l1, L2 = 1 << l2, tid = threadIdx.x, nthr = blockDim.x;
     const long L = (long)L1 << l2, N = L >> 1;
-    const int c0 = blockIdx.x * kColT;
+    const int tile = xcd_tile(blockIdx.x, gridDim.x), c0 = tile * kColT;
     const long item = first_item + blockIdx.y;
     // per-column twiddle tables W_L^(n2*e) = T1[e & (2^a-1)] * T2[e >> a] (n2*e < L: no reduction) and the W_L1 table
     const int a = l1 >> 1, na = 1 << a, nb = L1 >> a;
-    float2* tab = x + ((long)L1 << kColLogT);                 // [T][na + nb + 1]: an odd stride, or the 16 columns' reads of one
+    float2* tab = x + lp((long)L1 << kColLogT);                 // [T][na + nb + 1]: an odd stride, or the 16 columns' reads of one
     constexpr int kTabPad = 1;                                //   entry sit on two banks (8-way conflict)
     float2* twl = tab + (long)kColT * (na + nb + kTabPad);
     for (int k = tid; k < (L1 >> 1); k += nthr) twl[k] = tw[k];
@@ -788,7 +807,7 @@ __global__ __launch_bounds__(1024) void g_cols_fwd(const void* __restrict__ iq, 
     // (first pass from HBM / last pass to HBM measured slower here: 2.0 vs 1.58 ms on cfg2 -- the sink's table
     // lookups on top of a radix-16 pass spill)
     const int nz = (L1 >> 1) << kColLogT;                     // only the rows n1 < L1/2 are non-zero
-    for (int idx = nz + tid; idx < (L1 << kColLogT); idx += nthr) x[idx] = make_float2(0.f, 0.f);
+    for (int idx = nz + tid; idx < (L1 << kColLogT); idx += nthr) x[TileFwd::pos(idx)] = make_float2(0.f, 0.f);
     batched<8>(tid, nz, nthr,
                [&](int idx) -> float2 {
                    const long n = (long)(idx >> kColLogT) * L2 + c0 + (idx & (kColT - 1));
@@ -801,11 +820,11 @@ __global__ __launch_bounds__(1024) void g_cols_fwd(const void* __restrict__ iq, 
                    }
                    return rot ? rot_mul(v, rot[n]) : v;
                },
-               [&](int idx, float2 v) { x[idx] = v; });
+               [&](int idx, float2 v) { x[TileFwd::pos(idx)] = v; });
     __syncthreads();
     lds_dif<kColLogT>(x, l1, twl, tid, nthr);
     float2* o = out + (long)blockIdx.y * L;
-    batched<8>(tid, L1 << kColLogT, nthr, [&](int idx) -> float2 { return x[idx]; },
+    batched<8>(tid, L1 << kColLogT, nthr, [&](int idx) -> float2 { return x[TileFwd::pos(idx)]; },
                [&](int idx, float2 v) {
                    const int c = idx & (kColT - 1), pos = idx >> kColLogT;
                    const int k1 = brev(pos, l1);
@@ -832,9 +851,9 @@ __global__ __launch_bounds__(1024) void g_cols_inv(const float2* __restrict__ in
     const int L1 = 1 << l1, L2 = 1 << l2, tid = threadIdx.x, nthr = blockDim.x;
     const long L = (long)L1 << l2;
     const int N = (int)(L >> 1);
-    const int c0 = blockIdx.x * kColT;
-    float2* twl = x + ((long)L1 << kColLogT) + (long)kColT * ((1 << (l1 >> 1)) + (L1 >> (l1 >> 1)) + 1);
-    float* sv = reinterpret_cast<float*>(x + ((long)L1 << kColLogT));   // 16 + 16 words in the (unused here) table region
+    const int tile = xcd_tile(blockIdx.x, gridDim.x), c0 = tile * kColT;
+    float2* twl = x + lp((long)L1 << kColLogT) + (long)kColT * ((1 << (l1 >> 1)) + (L1 >> (l1 >> 1)) + 1);
+    float* sv = reinterpret_cast<float*>(x + lp((long)L1 << kColLogT));   // 16 + 16 words in the (unused here) table region
     int* sk = reinterpret_cast<int*>(sv + 16);
     for (int k = tid; k < (L1 >> 1); k += nthr) twl[k] = tw[k];
     const float2* src = in + (long)blockIdx.y * L;
@@ -853,14 +872,14 @@ __global__ __launch_bounds__(1024) void g_cols_inv(const float2* __restrict__ in
             const int k = full_index((int)m, N);
             const float v = e.x * e.x + e.y * e.y;
             if (k >= 0 && (v > best || (v == best && k < bk))) { best = v; bk = k; }
-            x[E0 + off] = make_float2(v, 0.0f);
+            x[TileInv::pos(E0) + TileInv::pos(off)] = make_float2(v, 0.0f);
         }));
     __syncthreads();
     // halo: |r|^2 of columns c0 and c0 + T - 1, all rows: [slot][tile][2][L1]
-    float* hb = halo + ((long)blockIdx.y * gridDim.x + blockIdx.x) * 2L * L1;
+    float* hb = halo + ((long)blockIdx.y * gridDim.x + tile) * 2L * L1;
     for (int n1 = tid; n1 < 2 * L1; n1 += nthr) {
         const int row = n1 & (L1 - 1), col = n1 < L1 ? 0 : kColT - 1;
-        hb[n1] = x[(row << kColLogT) + col].x;
+        hb[n1] = x[TileInv::pos((row << kColLogT) + col)].x;
     }
     block_argmax_w(best, bk, sv, sk, tid, nthr);
     if (tid == 0) {
@@ -873,10 +892,10 @@ __global__ __launch_bounds__(1024) void g_cols_inv(const float2* __restrict__ in
             const int c = (int)(m & (L2 - 1)) - c0, row = (int)(m >> l2);
             // 'full' neighbours are the circular neighbours m -+ 1 (the excluded lag -N sits between the two
             // ends of the 'full' range): inside this tile when the column is
-            if (c > 0) t.tm = x[(row << kColLogT) + c - 1].x;
-            if (c < kColT - 1) t.tp = x[(row << kColLogT) + c + 1].x;
+            if (c > 0) t.tm = x[TileInv::pos((row << kColLogT) + c - 1)].x;
+            if (c < kColT - 1) t.tp = x[TileInv::pos((row << kColLogT) + c + 1)].x;
         }
-        rec[(long)blockIdx.y * gridDim.x + blockIdx.x] = t;
+        rec[(long)blockIdx.y * gridDim.x + tile] = t;
     }
 }
 

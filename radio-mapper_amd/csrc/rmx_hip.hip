@@ -1387,7 +1387,7 @@ static size_t gen_fused_lds(int R) {                    // g_rows_fused: R/16 th
 }
 static size_t gen_cols_lds(int l1) {                    // [L1][T] tile + T per-column twiddle tables
     const int a = l1 >> 1, T = 1 << gen::col_log_t(l1);
-    return ((size_t)((long)(1 << l1) * T) + (size_t)T * ((1 << a) + ((1 << l1) >> a) + 1) + (size_t)((1 << l1) >> 1)) * 8;   // + W_L1 table
+    return ((size_t)gen::lp((long)(1 << l1) * T) + (size_t)T * ((1 << a) + ((1 << l1) >> a) + 1) + (size_t)((1 << l1) >> 1)) * 8;   // + W_L1 table
 }
 static int gen_cols_threads(int l1) {                   // one radix-16 work item per thread and pass, <= 1024
     const long work = (((long)1 << l1) << gen::col_log_t(l1)) / 16;
