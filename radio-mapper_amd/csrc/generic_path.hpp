@@ -502,22 +502,21 @@ __global__ __launch_bounds__(kGThreads) void g_rows(float2* __restrict__ data, c
     const int rpw = kGThreads / tpr;                                                   // rows per workgroup
     const int g = threadIdx.x / tpr, tid = threadIdx.x % tpr;
     float2* x = reinterpret_cast<float2*>(gsm) + (long)g * lp(R);
-    // the W_R table goes to LDS once per (persistent) workgroup (butterflies would otherwise fetch their twiddles
+    // the W_R table goes to LDS (butterflies would otherwise fetch their twiddles
     // through the vector memory path, a dependent cache-latency access in the inner loop)
     float2* twl = reinterpret_cast<float2*>(gsm) + (long)rpw * lp(R) + (TW ? (long)rpw * ((1 << (logR >> 1)) + (R >> (logR >> 1))) : 0);
     for (int k = threadIdx.x; k < (R >> 1); k += kGThreads) twl[k] = tw[k];
     static_assert((FWD && !TW && !PROD) || (!FWD && TW && PROD), "the two row passes of the four-step");
     const LdsIO lds{x};
-    const long n_blocks = (total_rows + rpw - 1) / rpw;
-    __syncthreads();                              // W_R table
-    // persistent: the workgroup walks blocks of rpw rows blockIdx.x, + gridDim.x, ... (the table above is half the
-    // size of a row: loading it per row was a third of this kernel's L2 traffic)
-    for (long blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
-    const long ridx = blk * rpw + g;
+    // (one block of rpw rows per workgroup.  A persistent variant -- the workgroup walking blocks blockIdx.x, +
+    // gridDim.x, ... with the W_R table loaded once -- measured 15 % slower on 2048-point rows and equal on 4096-point
+    // ones: hipcc schedules the loop body worse than the straight-line kernel.)
+    const long ridx = (long)blockIdx.x * rpw + g;
     const bool live = ridx < total_rows;
     float2* row = data + ridx * R;
     const int rib = (int)(ridx & (n_rows - 1));   // row index inside its batch element (n_rows = 2^row_bits)
     if constexpr (FWD) {
+        __syncthreads();                          // W_R table
         // forward rows: the first pass reads the row straight from HBM (its 2^M inputs are R / 2^M apart, so
         // consecutive threads read consecutive elements), the last leaves the spectrum in LDS for the store loop
         fft_dif<0>(x, logR, twl, tid, tpr, make_src([&](int E) -> float2 { return live ? row[E] : make_float2(0.f, 0.f); }), lds);
@@ -557,8 +556,6 @@ __global__ __launch_bounds__(kGThreads) void g_rows(float2* __restrict__ data, c
                 const float2 r = g_cmulc(x[lp(n)], w);
                 row[n] = make_float2(r.x * scale, r.y * scale);
             }
-    }
-    __syncthreads();                              // the next block's first pass / tables overwrite x, t1
     }
 }
 
@@ -691,6 +688,7 @@ __global__ __launch_bounds__(kGThreads, 2) void g_rows_fused(const float2* __res
     fused_tab_build<LOGR, LOGR>(twl, tw);
     const long n_blocks = (n_units + upw - 1) / upw;
     __syncthreads();
+    // (persistent: 4.22 ms against 4.34 ms with one block per workgroup on cfg2 -- the tables are 32 KiB)
     for (long blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
         // the block's units are rows rib0 .. rib0 + upw - 1 of one window (upw divides n_rows); addresses below are a
         // workgroup-uniform base (SGPRs) plus a 32-bit offset per thread

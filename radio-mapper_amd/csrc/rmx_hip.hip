@@ -1501,21 +1501,6 @@ static int generic_ensure(rmx_ctx* c, int n_pairs) {
     return RMX_OK;
 }
 
-// grid of the row kernels. Rows of 4096 points and more run persistent (as many workgroups as fit on the chip, each
-// loading the W_R table once: cfg2 5.79 -> 5.60 ms); shorter rows measured 2 % slower that way (L = 2^19: 1.56 vs
-// 1.59 ms) and keep one workgroup per block of rows.
-static dim3 rows_grid(const rmx_ctx* c, long rows, int rpw, size_t lds, int logR) {
-    const long blocks = (rows + rpw - 1) / rpw;
-    bool persist = logR >= 12;
-    if (const char* e = getenv("RMX_ROWS_PERSIST")) persist = atoi(e) != 0;
-    if (!persist) return dim3((unsigned)blocks);
-    long per_cu = (long)(160 * 1024 / (lds > 0 ? lds : 1));
-    if (per_cu > 8) per_cu = 8;
-    if (per_cu < 1) per_cu = 1;
-    const long resident = per_cu * c->n_cus;
-    return dim3((unsigned)(blocks < resident ? blocks : resident));
-}
-
 // forward spectra of windows [w0, w0 + wc) of d_iq into g_spec (rot == nullptr) or, de-rotated by the phasor
 // table rot[N], into g_spec_r (rmx_caf_batch)
 static int generic_forward(rmx_ctx* c, const void* d_iq, int w0, int wc, bool u8, const float2* rot,
@@ -1560,7 +1545,7 @@ static int generic_forward(rmx_ctx* c, const void* d_iq, int w0, int wc, bool u8
     }
     const long rows = (long)items * L1;
     const int rpw = kGThreads / tpr;
-    hipLaunchKernelGGL((g_rows<true, false, false>), rows_grid(c, rows, rpw, rlds, l2), dim3(kGThreads), rlds, st, dst,
+    hipLaunchKernelGGL((g_rows<true, false, false>), dim3((unsigned)((rows + rpw - 1) / rpw)), dim3(kGThreads), rlds, st, dst,
                        c->g_tw2, l2, L1, l1, L, c->g_lo_bits, c->g_thi, c->g_tlo, fwd_scale, rows, (const float2*)nullptr,
                        (const float2*)nullptr, (const GPair*)nullptr, 0, 0, tpr);
     RMX_HIP(c, hipGetLastError());
@@ -1610,7 +1595,7 @@ static int generic_pairs(rmx_ctx* c, int w0, int wc, int n_pairs, int* d_lag, fl
         void* args[] = {&colsp, &prodp, &twp, &a_L1, &a_l1, &a_L, &a_lo, &thip, &tlop, &a_scale, &a_units, &pp, &a_np};
         RMX_HIP(c, hipLaunchKernel(c->g_fused_fn, grid, dim3(kGThreads), args, gen_fused_lds(L2), st));
     } else
-    hipLaunchKernelGGL((g_rows<false, true, true>), rows_grid(c, rows, rpw, rlds, l2), dim3(kGThreads), rlds, st, c->g_prod,
+    hipLaunchKernelGGL((g_rows<false, true, true>), dim3((unsigned)((rows + rpw - 1) / rpw)), dim3(kGThreads), rlds, st, c->g_prod,
                        c->g_tw2, l2, L1, l1, L, c->g_lo_bits, c->g_thi, c->g_tlo, 1.0f, rows, (const float2*)c->g_spec, spec_j,
                        c->g_pairs, n_pairs, B, tpr);
     if (lt == 3)
