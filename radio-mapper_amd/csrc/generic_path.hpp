@@ -311,9 +311,11 @@ __device__ __forceinline__ void fft_dif(float2* x, int logR, const float2* __res
     dif_pass_m<LOGT>(b, logR, b, tw, tid, nthr, mid, last);
 }
 // DIT with conjugated twiddles: bit-reversed in -> natural out (inverse, unnormalised)
+// tw16 (optional, logR > 8): the second pass's own table [k = 1..15][l < 16] = W_R^(l k 2^(logR-8)) (build_tw16): its
+// reads of the shared table are 16 lanes 2^(logR-8) k entries apart -- all on one or two banks, an 8..16-way conflict
 template <int LOGT, class First, class Last>
 __device__ __forceinline__ void fft_dit_inv(float2* x, int logR, const float2* __restrict__ tw, int tid, int nthr,
-                                            const First& first, const Last& last) {
+                                            const First& first, const Last& last, const float2* __restrict__ tw16 = nullptr) {
     const LdsIOFor<LOGT, RMX_TILE_FLAT_INV != 0> mid{x};
     if (logR <= 4) {
         dit_pass_m<LOGT>(logR, logR, logR, tw, tid, nthr, first, last);
@@ -324,10 +326,14 @@ __device__ __forceinline__ void fft_dit_inv(float2* x, int logR, const float2* _
     int b = 0;
     for (; b + 4 < logR; b += 4) {
         if (b == 0) dit_pass<4, LOGT>(logR, 4, tw, tid, nthr, first, mid);
+        else if (b == 4 && tw16) dit_pass<4, LOGT, 2>(logR, 8, tw16, tid, nthr, mid, mid);
         else dit_pass<4, LOGT>(logR, b + 4, tw, tid, nthr, mid, mid);
         __syncthreads();
     }
     dit_pass_m<LOGT>(logR - b, logR, logR, tw, tid, nthr, mid, last);
+}
+__device__ __forceinline__ void build_tw16(float2* t, const float2* __restrict__ tw, int logR, int tid, int nthr) {
+    for (int e = tid; e < 240; e += nthr) t[e] = tw_full(tw, ((e & 15) << (logR - 8)) * ((e >> 4) + 1), 1 << (logR - 1));
 }
 // in place in LDS, barrier behind the last pass too
 template <int LOGT = 0>
@@ -506,11 +512,17 @@ __global__ __launch_bounds__(kGThreads) void g_rows(float2* __restrict__ data, c
     // through the vector memory path, a dependent cache-latency access in the inner loop)
     float2* twl = reinterpret_cast<float2*>(gsm) + (long)rpw * lp(R) + (TW ? (long)rpw * ((1 << (logR >> 1)) + (R >> (logR >> 1))) : 0);
     for (int k = threadIdx.x; k < (R >> 1); k += kGThreads) twl[k] = tw[k];
+    float2* tw16 = twl + (R >> 1);                // [15][16]: the inverse's q = 16 pass (fft_dit_inv)
+    // (rows of 4096 go without: three workgroups of 52 KiB share a CU, and 2 KiB more make it two -- 5.46 -> 5.88 ms)
+    const bool own16 = !FWD && logR > 8 && logR < 12;
+    if (own16) build_tw16(tw16, tw, logR, threadIdx.x, kGThreads);
     static_assert((FWD && !TW && !PROD) || (!FWD && TW && PROD), "the two row passes of the four-step");
     const LdsIO lds{x};
     // (one block of rpw rows per workgroup.  A persistent variant -- the workgroup walking blocks blockIdx.x, +
     // gridDim.x, ... with the W_R table loaded once -- measured 15 % slower on 2048-point rows and equal on 4096-point
     // ones: hipcc schedules the loop body worse than the straight-line kernel.)
+    // (slot-major.  Walking all pairs of a window over a block of 8 rows per XCD, so that the spectra rows stay in
+    // L2, measured 7 % SLOWER on cfg5: the kernel is not waiting for HBM reads.)
     const long ridx = (long)blockIdx.x * rpw + g;
     const bool live = ridx < total_rows;
     float2* row = data + ridx * R;
@@ -546,7 +558,7 @@ __global__ __launch_bounds__(kGThreads) void g_rows(float2* __restrict__ data, c
                        [&](int n, float4 v) { x[lp(n)] = g_cmulc(make_float2(v.x, v.y), make_float2(v.z, v.w)); });
         }
         __syncthreads();
-        fft_dit_inv<0>(x, logR, twl, tid, tpr, lds, lds);
+        fft_dit_inv<0>(x, logR, twl, tid, tpr, lds, lds, own16 ? tw16 : nullptr);
         __syncthreads();
         // (measured on cfg2: the last pass straight to HBM through the twiddle 1.73 ms, this loop batched eight
         // deep 2.05 ms, plain 1.68 ms)

@@ -1370,7 +1370,7 @@ static size_t gen_rows_lds(int R) {                     // rows + per-row twiddl
     int logR = 0;
     while ((1 << logR) < R) ++logR;
     const int a = logR >> 1;
-    return ((size_t)(gen::kGThreads / tpr) * ((size_t)gen::lp(R) + (1 << a) + (R >> a)) + (size_t)(R >> 1)) * 8;   // + W_R table
+    return ((size_t)(gen::kGThreads / tpr) * ((size_t)gen::lp(R) + (1 << a) + (R >> a)) + (size_t)(R >> 1) + (R < 4096 ? 240 : 0)) * 8;   // + W_R table + the q = 16 pass's own
 }
 static const void* fused_fn(int nb, int logR) {         // g_rows_fused<n_buoys, log2 row length>
 #define RMX_FF(NB) (logR == 9 ? (const void*)gen::g_rows_fused<NB, 9> : logR == 10 ? (const void*)gen::g_rows_fused<NB, 10> : \
