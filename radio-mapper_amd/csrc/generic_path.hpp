@@ -493,8 +493,9 @@ __device__ __forceinline__ float2 big_tw(long m, int lo_bits, const float2* __re
 //   PROD (inverse only): the row is not read from `data` but formed on the fly as
 //        X_j[row] conj(X_i[row]) from the spectra (slot = window-in-chunk * n_pairs + pair), which
 //        saves the product's own pass through HBM; the result is written to `data`.
-template <bool FWD, bool TW, bool PROD = false>
-__global__ __launch_bounds__(kGThreads) void g_rows(float2* __restrict__ data, const float2* __restrict__ tw, int logR,
+// LOGR > 0: the row length as a compile-time constant (pass loops unrolled, strides and LDS offsets immediates)
+template <bool FWD, bool TW, bool PROD = false, int LOGR = 0>
+__global__ __launch_bounds__(kGThreads) void g_rows(float2* __restrict__ data, const float2* __restrict__ tw, int logR_arg,
                                                     int n_rows, int row_bits, long Ltot, int lo_bits,
                                                     const float2* __restrict__ thi,
                                                     const float2* __restrict__ tlo, float scale, long total_rows,
@@ -503,8 +504,9 @@ __global__ __launch_bounds__(kGThreads) void g_rows(float2* __restrict__ data, c
                                                     const GPair* __restrict__ pairs = nullptr, int n_pairs = 0,
                                                     int n_buoys = 0, int tpr_arg = 0) {
     extern __shared__ __attribute__((aligned(16))) char gsm[];
+    const int logR = LOGR > 0 ? LOGR : logR_arg;
     const int R = 1 << logR;
-    const int tpr = tpr_arg > 0 ? tpr_arg : rows_tpr(R);                               // threads per row
+    const int tpr = LOGR > 0 ? rows_tpr(1 << LOGR) : (tpr_arg > 0 ? tpr_arg : rows_tpr(R));   // threads per row
     const int rpw = kGThreads / tpr;                                                   // rows per workgroup
     const int g = threadIdx.x / tpr, tid = threadIdx.x % tpr;
     float2* x = reinterpret_cast<float2*>(gsm) + (long)g * lp(R);

@@ -1176,6 +1176,7 @@ struct rmx_ctx {
     bool g_fused = false;      // four-step: both row passes in g_rows_fused (n_buoys <= 4, plain batches)
     int g_fused_wgs = 0;       // its persistent grid
     const void* g_fused_fn = nullptr;
+    const void* g_rows_inv_fn = nullptr;   // g_rows<inverse> compiled for this row length (or the run-time one)
     float2 *g_tw = nullptr, *g_tw1 = nullptr, *g_tw2 = nullptr, *g_thi = nullptr, *g_tlo = nullptr;
     float2 *g_spec = nullptr, *g_spec_r = nullptr, *g_prod = nullptr;   // spectra, de-rotated spectra (CAF), products
     rmx::gen::GTile* g_rec = nullptr;   // per column tile: partial argmax + taps
@@ -1372,6 +1373,18 @@ static size_t gen_rows_lds(int R) {                     // rows + per-row twiddl
     const int a = logR >> 1;
     return ((size_t)(gen::kGThreads / tpr) * ((size_t)gen::lp(R) + (1 << a) + (R >> a)) + (size_t)(R >> 1) + (R < 4096 ? 240 : 0)) * 8;   // + W_R table + the q = 16 pass's own
 }
+static const void* rows_inv_fn(int logR, int tpr) {       // the inverse row kernel, row length compiled in where we have it
+    using namespace gen;
+    if (tpr != rows_tpr(1 << logR)) return (const void*)g_rows<false, true, true>;      // RMX_ROWS_TPR override
+    switch (logR) {
+        case 9: return (const void*)g_rows<false, true, true, 9>;
+        case 10: return (const void*)g_rows<false, true, true, 10>;
+        case 11: return (const void*)g_rows<false, true, true, 11>;
+        case 12: return (const void*)g_rows<false, true, true, 12>;
+        case 13: return (const void*)g_rows<false, true, true, 13>;
+        default: return (const void*)g_rows<false, true, true>;
+    }
+}
 static const void* fused_fn(int nb, int logR) {         // g_rows_fused<n_buoys, log2 row length>
 #define RMX_FF(NB) (logR == 9 ? (const void*)gen::g_rows_fused<NB, 9> : logR == 10 ? (const void*)gen::g_rows_fused<NB, 10> : \
                     logR == 11 ? (const void*)gen::g_rows_fused<NB, 11> : (const void*)gen::g_rows_fused<NB, 12>)
@@ -1443,6 +1456,8 @@ static int generic_init(rmx_ctx* c) {
         RMX_HIP(c, hipFuncSetAttribute((const void*)(g_cols_inv<4>), hipFuncAttributeMaxDynamicSharedMemorySize, cols_lds));
         RMX_HIP(c, hipFuncSetAttribute((const void*)(g_rows<true, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, rows_lds));
         RMX_HIP(c, hipFuncSetAttribute((const void*)(g_rows<false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, rows_lds));
+        c->g_rows_inv_fn = rows_inv_fn(c->g_logL2, gen_rows_tpr(1 << c->g_logL2));
+        RMX_HIP(c, hipFuncSetAttribute(c->g_rows_inv_fn, hipFuncAttributeMaxDynamicSharedMemorySize, rows_lds));
         // both row passes in one kernel when the buoys' spectra rows fit the register file (generic_path.hpp)
         c->g_fused = c->n_buoys <= 4 && c->g_logL2 >= 9 && c->g_logL2 <= 12;
         if (const char* e = getenv("RMX_FUSED")) c->g_fused = c->g_fused && atoi(e) != 0;
@@ -1595,9 +1610,17 @@ static int generic_pairs(rmx_ctx* c, int w0, int wc, int n_pairs, int* d_lag, fl
         void* args[] = {&colsp, &prodp, &twp, &a_L1, &a_l1, &a_L, &a_lo, &thip, &tlop, &a_scale, &a_units, &pp, &a_np};
         RMX_HIP(c, hipLaunchKernel(c->g_fused_fn, grid, dim3(kGThreads), args, gen_fused_lds(L2), st));
     } else
-    hipLaunchKernelGGL((g_rows<false, true, true>), dim3((unsigned)((rows + rpw - 1) / rpw)), dim3(kGThreads), rlds, st, c->g_prod,
-                       c->g_tw2, l2, L1, l1, L, c->g_lo_bits, c->g_thi, c->g_tlo, 1.0f, rows, (const float2*)c->g_spec, spec_j,
-                       c->g_pairs, n_pairs, B, tpr);
+    {
+        float2* a_data = c->g_prod;
+        const float2 *a_tw = c->g_tw2, *a_thi = c->g_thi, *a_tlo = c->g_tlo, *a_spec = c->g_spec, *a_specj = spec_j;
+        const GPair* a_pairs = c->g_pairs;
+        int a_l2 = l2, a_L1 = L1, a_l1 = l1, a_lo = c->g_lo_bits, a_np = n_pairs, a_B = B, a_tpr = tpr;
+        long a_L = L, a_rows = rows;
+        float a_scale = 1.0f;
+        void* args[] = {&a_data, &a_tw, &a_l2, &a_L1, &a_l1, &a_L, &a_lo, &a_thi, &a_tlo, &a_scale, &a_rows, &a_spec, &a_specj,
+                        &a_pairs, &a_np, &a_B, &a_tpr};
+        RMX_HIP(c, hipLaunchKernel(c->g_rows_inv_fn, dim3((unsigned)((rows + rpw - 1) / rpw)), dim3(kGThreads), args, rlds, st));
+    }
     if (lt == 3)
         hipLaunchKernelGGL((g_cols_inv<3>), dim3(ntiles, slots), dim3(cthr), clds, st, c->g_prod, c->g_tw1, l1, l2, c->g_rec,
                            c->g_halo);
