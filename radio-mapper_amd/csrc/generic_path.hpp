@@ -791,16 +791,22 @@ __device__ __forceinline__ int xcd_tile(int bid, int n) {
     return (n & 7) == 0 ? (bid & 7) * (n >> 3) + (bid >> 3) : bid;
 #endif
 }
-template <bool U8, int kColLogT>
+// threads of a column kernel: one radix-16 work item per thread and pass, 64 .. 1024
+__host__ __device__ constexpr int cols_threads(int l1, int log_t) {
+    return ((1 << l1) << log_t) / 16 >= 1024 ? 1024 : (((1 << l1) << log_t) / 16 < 64 ? 64 : ((1 << l1) << log_t) / 16);
+}
+// L1C > 0: the column length (and with it the thread count) as compile-time constants
+template <bool U8, int kColLogT, int L1C = 0>
 __global__ __launch_bounds__(1024) void g_cols_fwd(const void* __restrict__ iq, float2* __restrict__ out,
-                                                   const float2* __restrict__ tw, int l1, int l2, long first_item,
+                                                   const float2* __restrict__ tw, int l1_arg, int l2, long first_item,
                                                    int lo_bits, const float2* __restrict__ thi,
                                                    const float2* __restrict__ tlo,
                                                    const float2* __restrict__ rot = nullptr) {
     constexpr int kColT = 1 << kColLogT;
     extern __shared__ __attribute__((aligned(16))) char gsm[];
     float2* x = reinterpret_cast<float2*>(gsm);
-    const int L1 = 1 << l1, L2 = 1 << l2, tid = threadIdx.x, nthr = blockDim.x;
+    const int l1 = L1C > 0 ? L1C : l1_arg;
+    const int L1 = 1 << l1, L2 = 1 << l2, tid = threadIdx.x, nthr = L1C > 0 ? cols_threads(L1C, kColLogT) : (int)blockDim.x;
     const long L = (long)L1 << l2, N = L >> 1;
     const int tile = xcd_tile(blockIdx.x, gridDim.x), c0 = tile * kColT;
     const long item = first_item + blockIdx.y;
@@ -854,13 +860,14 @@ struct GTile {
     int k;          // its lowest 'full' index
     float tm, tp;   // |r|^2 at k-1, k+1, or -1 where that lag lives in another tile (or does not exist)
 };
-template <int kColLogT>
-__global__ __launch_bounds__(1024) void g_cols_inv(const float2* __restrict__ in, const float2* __restrict__ tw, int l1,
+template <int kColLogT, int L1C = 0>
+__global__ __launch_bounds__(1024) void g_cols_inv(const float2* __restrict__ in, const float2* __restrict__ tw, int l1_arg,
                                                    int l2, GTile* __restrict__ rec, float* __restrict__ halo) {
     constexpr int kColT = 1 << kColLogT;
     extern __shared__ __attribute__((aligned(16))) char gsm[];
     float2* x = reinterpret_cast<float2*>(gsm);
-    const int L1 = 1 << l1, L2 = 1 << l2, tid = threadIdx.x, nthr = blockDim.x;
+    const int l1 = L1C > 0 ? L1C : l1_arg;
+    const int L1 = 1 << l1, L2 = 1 << l2, tid = threadIdx.x, nthr = L1C > 0 ? cols_threads(L1C, kColLogT) : (int)blockDim.x;
     const long L = (long)L1 << l2;
     const int N = (int)(L >> 1);
     const int tile = xcd_tile(blockIdx.x, gridDim.x), c0 = tile * kColT;

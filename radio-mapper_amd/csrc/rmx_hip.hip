@@ -1176,6 +1176,8 @@ struct rmx_ctx {
     bool g_fused = false;      // four-step: both row passes in g_rows_fused (n_buoys <= 4, plain batches)
     int g_fused_wgs = 0;       // its persistent grid
     const void* g_fused_fn = nullptr;
+    const void* g_cols_inv_fn = nullptr;
+    const void* g_cols_fwd_fn[2] = {nullptr, nullptr};   // [u8]
     const void* g_rows_inv_fn = nullptr;   // g_rows<inverse> compiled for this row length (or the run-time one)
     float2 *g_tw = nullptr, *g_tw1 = nullptr, *g_tw2 = nullptr, *g_thi = nullptr, *g_tlo = nullptr;
     float2 *g_spec = nullptr, *g_spec_r = nullptr, *g_prod = nullptr;   // spectra, de-rotated spectra (CAF), products
@@ -1373,6 +1375,32 @@ static size_t gen_rows_lds(int R) {                     // rows + per-row twiddl
     const int a = logR >> 1;
     return ((size_t)(gen::kGThreads / tpr) * ((size_t)gen::lp(R) + (1 << a) + (R >> a)) + (size_t)(R >> 1) + (R < 4096 ? 240 : 0)) * 8;   // + W_R table + the q = 16 pass's own
 }
+// column kernels with the column length compiled in (16-column tiles, the default thread count), else the run-time ones
+static const void* cols_inv_fn(int l1, int lt, int thr) {
+    using namespace gen;
+    if (lt == 3) return (const void*)g_cols_inv<3>;
+    if (thr == cols_threads(l1, 4)) switch (l1) {
+        case 6: return (const void*)g_cols_inv<4, 6>;
+        case 7: return (const void*)g_cols_inv<4, 7>;
+        case 8: return (const void*)g_cols_inv<4, 8>;
+        case 9: return (const void*)g_cols_inv<4, 9>;
+        default: break;
+    }
+    return (const void*)g_cols_inv<4>;
+}
+template <bool U8>
+static const void* cols_fwd_fn(int l1, int lt, int thr) {
+    using namespace gen;
+    if (lt == 3) return (const void*)g_cols_fwd<U8, 3>;
+    if (thr == cols_threads(l1, 4)) switch (l1) {
+        case 6: return (const void*)g_cols_fwd<U8, 4, 6>;
+        case 7: return (const void*)g_cols_fwd<U8, 4, 7>;
+        case 8: return (const void*)g_cols_fwd<U8, 4, 8>;
+        case 9: return (const void*)g_cols_fwd<U8, 4, 9>;
+        default: break;
+    }
+    return (const void*)g_cols_fwd<U8, 4>;
+}
 static const void* rows_inv_fn(int logR, int tpr) {       // the inverse row kernel, row length compiled in where we have it
     using namespace gen;
     if (tpr != rows_tpr(1 << logR)) return (const void*)g_rows<false, true, true>;      // RMX_ROWS_TPR override
@@ -1448,12 +1476,15 @@ static int generic_init(rmx_ctx* c) {
         rc = upload(c, &c->g_tlo, tlo);
         if (rc) return rc;
         const int cols_lds = (int)gen_cols_lds(c->g_logL1), rows_lds = (int)gen_rows_lds(1 << c->g_logL2);
-        RMX_HIP(c, hipFuncSetAttribute((const void*)(g_cols_fwd<false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, cols_lds));
-        RMX_HIP(c, hipFuncSetAttribute((const void*)(g_cols_fwd<true, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, cols_lds));
-        RMX_HIP(c, hipFuncSetAttribute((const void*)(g_cols_inv<3>), hipFuncAttributeMaxDynamicSharedMemorySize, cols_lds));
-        RMX_HIP(c, hipFuncSetAttribute((const void*)(g_cols_fwd<false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, cols_lds));
-        RMX_HIP(c, hipFuncSetAttribute((const void*)(g_cols_fwd<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, cols_lds));
-        RMX_HIP(c, hipFuncSetAttribute((const void*)(g_cols_inv<4>), hipFuncAttributeMaxDynamicSharedMemorySize, cols_lds));
+        {
+            const int lt = col_log_t(c->g_logL1), thr = gen_cols_threads(c->g_logL1);
+            c->g_cols_inv_fn = cols_inv_fn(c->g_logL1, lt, thr);
+            c->g_cols_fwd_fn[0] = cols_fwd_fn<false>(c->g_logL1, lt, thr);
+            c->g_cols_fwd_fn[1] = cols_fwd_fn<true>(c->g_logL1, lt, thr);
+            RMX_HIP(c, hipFuncSetAttribute(c->g_cols_inv_fn, hipFuncAttributeMaxDynamicSharedMemorySize, cols_lds));
+            RMX_HIP(c, hipFuncSetAttribute(c->g_cols_fwd_fn[0], hipFuncAttributeMaxDynamicSharedMemorySize, cols_lds));
+            RMX_HIP(c, hipFuncSetAttribute(c->g_cols_fwd_fn[1], hipFuncAttributeMaxDynamicSharedMemorySize, cols_lds));
+        }
         RMX_HIP(c, hipFuncSetAttribute((const void*)(g_rows<true, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, rows_lds));
         RMX_HIP(c, hipFuncSetAttribute((const void*)(g_rows<false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, rows_lds));
         c->g_rows_inv_fn = rows_inv_fn(c->g_logL2, gen_rows_tpr(1 << c->g_logL2));
@@ -1548,12 +1579,15 @@ static int generic_forward(rmx_ctx* c, const void* d_iq, int w0, int wc, bool u8
     const size_t clds = gen_cols_lds(l1), rlds = gen_rows_lds(L2);
     const int lt = col_log_t(l1), ntiles = L2 >> lt;
     // column pass (zero-padded window -> [k1'][n2] * W_L^(n2 k1)), row pass in place (-> [k1'][k2'])
-#define RMX_COLS_FWD(U8V, LT)                                                                                          \
-    hipLaunchKernelGGL((g_cols_fwd<U8V, LT>), dim3(ntiles, items), dim3(cthr), clds, st, d_iq, dst, c->g_tw1, l1, l2,  \
-                       first_item, c->g_lo_bits, c->g_thi, c->g_tlo, rot)
-    if (u8) { if (lt == 3) RMX_COLS_FWD(true, 3); else RMX_COLS_FWD(true, 4); }
-    else    { if (lt == 3) RMX_COLS_FWD(false, 3); else RMX_COLS_FWD(false, 4); }
-#undef RMX_COLS_FWD
+    {
+        const void* a_iq = d_iq;
+        float2* a_out = dst;
+        const float2 *a_tw = c->g_tw1, *a_thi = c->g_thi, *a_tlo = c->g_tlo, *a_rot = rot;
+        int a_l1 = l1, a_l2 = l2, a_lo = c->g_lo_bits;
+        long a_first = first_item;
+        void* args[] = {&a_iq, &a_out, &a_tw, &a_l1, &a_l2, &a_first, &a_lo, &a_thi, &a_tlo, &a_rot};
+        RMX_HIP(c, hipLaunchKernel(c->g_cols_fwd_fn[u8 ? 1 : 0], dim3(ntiles, items), dim3(cthr), args, clds, st));
+    }
     if (cols_only) {                      // g_rows_fused does the rows
         RMX_HIP(c, hipGetLastError());
         return RMX_OK;
@@ -1621,12 +1655,14 @@ static int generic_pairs(rmx_ctx* c, int w0, int wc, int n_pairs, int* d_lag, fl
                         &a_pairs, &a_np, &a_B, &a_tpr};
         RMX_HIP(c, hipLaunchKernel(c->g_rows_inv_fn, dim3((unsigned)((rows + rpw - 1) / rpw)), dim3(kGThreads), args, rlds, st));
     }
-    if (lt == 3)
-        hipLaunchKernelGGL((g_cols_inv<3>), dim3(ntiles, slots), dim3(cthr), clds, st, c->g_prod, c->g_tw1, l1, l2, c->g_rec,
-                           c->g_halo);
-    else
-        hipLaunchKernelGGL((g_cols_inv<4>), dim3(ntiles, slots), dim3(cthr), clds, st, c->g_prod, c->g_tw1, l1, l2, c->g_rec,
-                           c->g_halo);
+    {
+        const float2 *a_in = c->g_prod, *a_tw = c->g_tw1;
+        int a_l1 = l1, a_l2 = l2;
+        GTile* a_rec = c->g_rec;
+        float* a_halo = c->g_halo;
+        void* args[] = {&a_in, &a_tw, &a_l1, &a_l2, &a_rec, &a_halo};
+        RMX_HIP(c, hipLaunchKernel(c->g_cols_inv_fn, dim3(ntiles, slots), dim3(cthr), args, clds, st));
+    }
     hipLaunchKernelGGL(g_final, dim3(slots), dim3(64), 0, st, N, l1, l2, lt, c->g_rec, c->g_halo, ntiles, slots,
                        (long)w0 * n_pairs, out_scale, d_lag, d_frac, d_peak);
     RMX_HIP(c, hipGetLastError());
