@@ -599,3 +599,25 @@ def test_alternative_window_kernels(xc, golden_dir, opt):
             l1, f1, p1 = eng.correlate(x)
         assert np.array_equal(l0, l1)
         assert np.allclose(l0 + f0, l1 + f1, atol=TOL) and np.allclose(p0, p1, rtol=1e-5)
+
+
+@pytest.mark.parametrize("N,B", [(16384, 2), (16384, 4), (32768, 3), (65536, 4), (131072, 2), (262144, 4), (524288, 3)])
+def test_fused_row_kernel_by_row_length(xc, N, B, monkeypatch):
+    """Four-step engines with up to 4 buoys run both row passes in one kernel (g_rows_fused, compiled for rows of
+    2^9 .. 2^12 points): every row length and buoy count against the oracle, a custom pair list with a reversed
+    pair through the same kernel, and the two-kernel row passes (RMX_FUSED=0) on the same input."""
+    W = 2
+    iq, _ = rm.synth.make_windows(W, B, N, 2.4e6, seed=900 + B + N % 991)
+    ri, rf, rp = orc.xcorr_batch_literal(iq)
+    margin = np.array([[orc.peak_margin(iq[w, i], iq[w, j]) for (i, j) in orc.pair_list(B)] for w in range(W)])
+    custom = np.array([(B - 1, 0), (0, 1)], np.int32)
+    with xc.XcorrEngine(B, N, W) as eng:
+        li, lf, pk = eng.correlate(iq)
+        ci, cf, cp = eng.correlate(iq, custom)
+    _assert_parity(li, lf, pk, ri, rf, rp, margin)
+    oi, of_, op = orc.xcorr_batch_literal(iq, custom)
+    _assert_parity(ci, cf, cp, oi, of_, op)
+    monkeypatch.setenv("RMX_FUSED", "0")
+    with xc.XcorrEngine(B, N, W) as eng:
+        ui, uf, up = eng.correlate(iq)
+    assert np.array_equal(ui, li) and np.all(np.abs(uf - lf) <= TOL) and np.allclose(up, pk, rtol=1e-5)
