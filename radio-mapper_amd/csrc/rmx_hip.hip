@@ -1360,7 +1360,13 @@ static int upload(rmx_ctx* c, float2** dst, const std::vector<float2>& v) {
 }
 
 // windows up to this zero-padded length run with the whole transform in LDS (128 KiB of the 160)
-static constexpr long kGenSmallMaxL = 16384;
+// (L = 16384 -- N = 8192, the reference's iq_stream_client capture length -- is better off in the four-step path: one
+// 128 KiB transform per CU leaves nothing to overlap with; 0.77 -> 0.60 ms for 3 buoys x 1024 windows)
+static long gen_small_max_l() {
+    static const long v = [] { const char* e = getenv("RMX_SMALL_MAXL"); const long x = e ? atol(e) : 0; return x >= 256 && x <= 16384 ? x : 8192L; }();
+    return v;
+}
+#define kGenSmallMaxL gen_small_max_l()
 static int gen_small_threads(long L) { const long t = L >> 4; return t >= 1024 ? 1024 : (t < 64 ? 64 : (int)t); }   // one radix-16 group per thread and pass
 // dynamic LDS of the four-step kernels
 static int gen_rows_tpr(int R) {
@@ -1380,6 +1386,7 @@ static const void* cols_inv_fn(int l1, int lt, int thr) {
     using namespace gen;
     if (lt == 3) return (const void*)g_cols_inv<3>;
     if (thr == cols_threads(l1, 4)) switch (l1) {
+        case 5: return (const void*)g_cols_inv<4, 5>;
         case 6: return (const void*)g_cols_inv<4, 6>;
         case 7: return (const void*)g_cols_inv<4, 7>;
         case 8: return (const void*)g_cols_inv<4, 8>;
@@ -1393,6 +1400,7 @@ static const void* cols_fwd_fn(int l1, int lt, int thr) {
     using namespace gen;
     if (lt == 3) return (const void*)g_cols_fwd<U8, 3>;
     if (thr == cols_threads(l1, 4)) switch (l1) {
+        case 5: return (const void*)g_cols_fwd<U8, 4, 5>;
         case 6: return (const void*)g_cols_fwd<U8, 4, 6>;
         case 7: return (const void*)g_cols_fwd<U8, 4, 7>;
         case 8: return (const void*)g_cols_fwd<U8, 4, 8>;
