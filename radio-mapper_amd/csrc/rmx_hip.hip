@@ -1178,7 +1178,8 @@ struct rmx_ctx {
     const void* g_fused_fn = nullptr;
     const void* g_cols_inv_fn = nullptr;
     const void* g_cols_fwd_fn[2] = {nullptr, nullptr};   // [u8]
-    const void* g_rows_inv_fn = nullptr;   // g_rows<inverse> compiled for this row length (or the run-time one)
+    const void* g_rows_inv_fn = nullptr;
+    const void* g_rows_fwd_fn = nullptr;   // g_rows<inverse> compiled for this row length (or the run-time one)
     float2 *g_tw = nullptr, *g_tw1 = nullptr, *g_tw2 = nullptr, *g_thi = nullptr, *g_tlo = nullptr;
     float2 *g_spec = nullptr, *g_spec_r = nullptr, *g_prod = nullptr;   // spectra, de-rotated spectra (CAF), products
     rmx::gen::GTile* g_rec = nullptr;   // per column tile: partial argmax + taps
@@ -1409,6 +1410,18 @@ static const void* cols_fwd_fn(int l1, int lt, int thr) {
     }
     return (const void*)g_cols_fwd<U8, 4>;
 }
+static const void* rows_fwd_fn(int logR, int tpr) {
+    using namespace gen;
+    if (tpr != rows_tpr(1 << logR)) return (const void*)g_rows<true, false, false>;
+    switch (logR) {
+        case 9: return (const void*)g_rows<true, false, false, 9>;
+        case 10: return (const void*)g_rows<true, false, false, 10>;
+        case 11: return (const void*)g_rows<true, false, false, 11>;
+        case 12: return (const void*)g_rows<true, false, false, 12>;
+        case 13: return (const void*)g_rows<true, false, false, 13>;
+        default: return (const void*)g_rows<true, false, false>;
+    }
+}
 static const void* rows_inv_fn(int logR, int tpr) {       // the inverse row kernel, row length compiled in where we have it
     using namespace gen;
     if (tpr != rows_tpr(1 << logR)) return (const void*)g_rows<false, true, true>;      // RMX_ROWS_TPR override
@@ -1434,12 +1447,16 @@ static size_t gen_fused_lds(int R) {                    // g_rows_fused: R/16 th
     const int buf = logR == 9 ? gen::FusedPlan<9>::buf : logR == 10 ? gen::FusedPlan<10>::buf : logR == 11 ? gen::FusedPlan<11>::buf : gen::FusedPlan<12>::buf;
     return ((size_t)upw * ((size_t)buf + (1 << a) + (R >> a)) + (size_t)gen::fused_tab_total(logR)) * 8;   // + the passes' twiddle tables
 }
+static int host_col_log_t(int l1) {                     // gen::col_log_t, or RMX_COL_LOGT (3 | 4) for experiments
+    if (const char* e = getenv("RMX_COL_LOGT")) { const int v = atoi(e); if (v == 3 || v == 4) return v; }
+    return gen::col_log_t(l1);
+}
 static size_t gen_cols_lds(int l1) {                    // [L1][T] tile + T per-column twiddle tables
-    const int a = l1 >> 1, T = 1 << gen::col_log_t(l1);
+    const int a = l1 >> 1, T = 1 << host_col_log_t(l1);
     return ((size_t)gen::lp((long)(1 << l1) * T) + (size_t)T * ((1 << a) + ((1 << l1) >> a) + 1) + (size_t)((1 << l1) >> 1)) * 8;   // + W_L1 table
 }
 static int gen_cols_threads(int l1) {                   // one radix-16 work item per thread and pass, <= 1024
-    const long work = (((long)1 << l1) << gen::col_log_t(l1)) / 16;
+    const long work = (((long)1 << l1) << host_col_log_t(l1)) / 16;
     if (const char* e = getenv("RMX_COLS_THREADS")) { const int v = atoi(e); if (v >= 64 && v <= 1024) return v; }
     return work >= 1024 ? 1024 : (work < 64 ? 64 : (int)work);
 }
@@ -1485,7 +1502,7 @@ static int generic_init(rmx_ctx* c) {
         if (rc) return rc;
         const int cols_lds = (int)gen_cols_lds(c->g_logL1), rows_lds = (int)gen_rows_lds(1 << c->g_logL2);
         {
-            const int lt = col_log_t(c->g_logL1), thr = gen_cols_threads(c->g_logL1);
+            const int lt = host_col_log_t(c->g_logL1), thr = gen_cols_threads(c->g_logL1);
             c->g_cols_inv_fn = cols_inv_fn(c->g_logL1, lt, thr);
             c->g_cols_fwd_fn[0] = cols_fwd_fn<false>(c->g_logL1, lt, thr);
             c->g_cols_fwd_fn[1] = cols_fwd_fn<true>(c->g_logL1, lt, thr);
@@ -1496,6 +1513,8 @@ static int generic_init(rmx_ctx* c) {
         RMX_HIP(c, hipFuncSetAttribute((const void*)(g_rows<true, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, rows_lds));
         RMX_HIP(c, hipFuncSetAttribute((const void*)(g_rows<false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, rows_lds));
         c->g_rows_inv_fn = rows_inv_fn(c->g_logL2, gen_rows_tpr(1 << c->g_logL2));
+        c->g_rows_fwd_fn = rows_fwd_fn(c->g_logL2, gen_rows_tpr(1 << c->g_logL2));
+        RMX_HIP(c, hipFuncSetAttribute(c->g_rows_fwd_fn, hipFuncAttributeMaxDynamicSharedMemorySize, rows_lds));
         RMX_HIP(c, hipFuncSetAttribute(c->g_rows_inv_fn, hipFuncAttributeMaxDynamicSharedMemorySize, rows_lds));
         // both row passes in one kernel when the buoys' spectra rows fit the register file (generic_path.hpp)
         c->g_fused = c->n_buoys <= 4 && c->g_logL2 >= 9 && c->g_logL2 <= 12;
@@ -1537,7 +1556,7 @@ static int generic_ensure(rmx_ctx* c, int n_pairs) {
             if (c->g_halo) { (void)hipFree(c->g_halo); c->g_halo = nullptr; }
             c->g_slots_alloc = 0;
             RMX_HIP(c, hipMalloc((void**)&c->g_prod, slots * L * 8));
-            const long parts = (1L << c->g_logL2) >> col_log_t(c->g_logL1);   // one record per column tile
+            const long parts = (1L << c->g_logL2) >> host_col_log_t(c->g_logL1);   // one record per column tile
             RMX_HIP(c, hipMalloc((void**)&c->g_rec, slots * parts * sizeof(GTile)));
             RMX_HIP(c, hipMalloc((void**)&c->g_halo, slots * parts * 2 * sizeof(float) << c->g_logL1));
             c->scratch_bytes += slots * L * 8 + slots * parts * (sizeof(GTile) + (2 * sizeof(float) << c->g_logL1));
@@ -1585,7 +1604,7 @@ static int generic_forward(rmx_ctx* c, const void* d_iq, int w0, int wc, bool u8
     const int l1 = c->g_logL1, l2 = c->g_logL2, L1 = 1 << l1, L2 = 1 << l2;
     const int cthr = gen_cols_threads(l1), tpr = gen_rows_tpr(L2);
     const size_t clds = gen_cols_lds(l1), rlds = gen_rows_lds(L2);
-    const int lt = col_log_t(l1), ntiles = L2 >> lt;
+    const int lt = host_col_log_t(l1), ntiles = L2 >> lt;
     // column pass (zero-padded window -> [k1'][n2] * W_L^(n2 k1)), row pass in place (-> [k1'][k2'])
     {
         const void* a_iq = d_iq;
@@ -1602,9 +1621,17 @@ static int generic_forward(rmx_ctx* c, const void* d_iq, int w0, int wc, bool u8
     }
     const long rows = (long)items * L1;
     const int rpw = kGThreads / tpr;
-    hipLaunchKernelGGL((g_rows<true, false, false>), dim3((unsigned)((rows + rpw - 1) / rpw)), dim3(kGThreads), rlds, st, dst,
-                       c->g_tw2, l2, L1, l1, L, c->g_lo_bits, c->g_thi, c->g_tlo, fwd_scale, rows, (const float2*)nullptr,
-                       (const float2*)nullptr, (const GPair*)nullptr, 0, 0, tpr);
+    {
+        float2* a_data = dst;
+        const float2 *a_tw = c->g_tw2, *a_thi = c->g_thi, *a_tlo = c->g_tlo, *a_null = nullptr;
+        const GPair* a_pairs = nullptr;
+        int a_l2 = l2, a_L1 = L1, a_l1 = l1, a_lo = c->g_lo_bits, a_zero = 0, a_tpr = tpr;
+        long a_L = L, a_rows = rows;
+        float a_scale = fwd_scale;
+        void* args[] = {&a_data, &a_tw, &a_l2, &a_L1, &a_l1, &a_L, &a_lo, &a_thi, &a_tlo, &a_scale, &a_rows, &a_null, &a_null,
+                        &a_pairs, &a_zero, &a_zero, &a_tpr};
+        RMX_HIP(c, hipLaunchKernel(c->g_rows_fwd_fn, dim3((unsigned)((rows + rpw - 1) / rpw)), dim3(kGThreads), args, rlds, st));
+    }
     RMX_HIP(c, hipGetLastError());
     return RMX_OK;
 }
@@ -1631,7 +1658,7 @@ static int generic_pairs(rmx_ctx* c, int w0, int wc, int n_pairs, int* d_lag, fl
     const int l1 = c->g_logL1, l2 = c->g_logL2, L1 = 1 << l1, L2 = 1 << l2;
     const int cthr = gen_cols_threads(l1), tpr = gen_rows_tpr(L2);
     const size_t clds = gen_cols_lds(l1), rlds = gen_rows_lds(L2);
-    const int lt = col_log_t(l1), ntiles = L2 >> lt;
+    const int lt = host_col_log_t(l1), ntiles = L2 >> lt;
     const long rows = (long)slots * L1;
     const int rpw = kGThreads / tpr;
     // row pass ([product on load] rows(L2)^-1 * conj W_L^(n2 k1)), column pass (-> tile records + halo), reduction
