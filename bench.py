@@ -451,8 +451,11 @@ def main():
             # multi-kernel paths: the figure is for the whole kernel sequence of one step (HIP events on the
             # launch stream around the timed region); per-kernel durations are in profiles/r02_<cfg>_*
             launches_per_step = 1.0
-            kernel = ("rmx_caf_batch kernel sequence (augment, forward, pair, select per Doppler bin)" if caf else
-                      "four-step sequence g_cols_fwd + g_rows + g_rows(product) + g_cols_inv + g_final")
+            kernel = ("rmx_caf_batch kernel sequence (un-rotated spectra once; per Doppler bin: de-rotated forward "
+                      "g_cols_fwd + g_rows, g_rows(product, inverse), g_cols_inv, g_final, k_caf_select)" if caf else
+                      ("four-step sequence g_cols_fwd + g_rows_fused (forward rows, products, inverse rows) + g_cols_inv "
+                       "+ g_final" if B <= 4 else
+                       "four-step sequence g_cols_fwd + g_rows + g_rows(product, inverse) + g_cols_inv + g_final"))
             launch_ms = region_ms / steps
             isolated_launch_ms = None
         alg_bytes_per_launch = alg_bytes_per_step_gpu / launches_per_step
