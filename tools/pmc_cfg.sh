@@ -21,9 +21,14 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         agg[r["Kernel_Name"].split("(")[0][:40]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+import json
+out = {}
 for k, d in agg.items():
     if "g_" not in k: continue
     print(k)
+    out[k] = {}
     for c, v in sorted(d.items()):
         print(f"   {c:24s} n={len(v):3d} mean={sum(v)/len(v):.4g}")
+        out[k][c] = sum(v) / len(v)
+json.dump(out, open(sys.argv[1] + "/summary.json", "w"), indent=1)
 PY
