@@ -29,6 +29,7 @@
 
 #include <cmath>
 #include <type_traits>
+#include <utility>
 #include <vector>
 
 namespace rmx {
@@ -187,6 +188,19 @@ struct DstFn {
         __device__ __forceinline__ void st(int o, float2 v) const { f(E0, o, v); }
     };
     __device__ __forceinline__ H open(int E0) const { return H{f, E0}; }
+};
+// a first-pass source whose elements from offset zoff on (the zero-padded half of a column) are zero: no load, and
+// with compile-time strides the butterfly's additions of those inputs fold away
+template <class IO>
+struct SrcZeroTail {
+    IO io;
+    int zoff;
+    struct H {
+        decltype(std::declval<IO>().open(0)) h;
+        int zoff;
+        __device__ __forceinline__ float2 ld(int o) const { return o >= zoff ? make_float2(0.f, 0.f) : h.ld(o); }
+    };
+    __device__ __forceinline__ H open(int E0) const { return H{io.open(E0), zoff}; }
 };
 template <class F>
 __device__ __forceinline__ SrcFn<F> make_src(F f) { return SrcFn<F>{f}; }
@@ -826,9 +840,8 @@ __global__ __launch_bounds__(1024) void g_cols_fwd(const void* __restrict__ iq, 
     __syncthreads();
     // (first pass from HBM / last pass to HBM measured slower here: 2.0 vs 1.58 ms on cfg2 -- the sink's table
     // lookups on top of a radix-16 pass spill)
-    const int nz = (L1 >> 1) << kColLogT;                     // only the rows n1 < L1/2 are non-zero
-    for (int idx = nz + tid; idx < (L1 << kColLogT); idx += nthr) x[TileFwd::pos(idx)] = make_float2(0.f, 0.f);
-    batched<8>(tid, nz, nthr,
+    const int nz = (L1 >> 1) << kColLogT;                     // only the rows n1 < L1/2 are non-zero: the others are
+    batched<8>(tid, nz, nthr,                                 // neither filled nor read (first pass below)
                [&](int idx) -> float2 {
                    const long n = (long)(idx >> kColLogT) * L2 + c0 + (idx & (kColT - 1));
                    float2 v;
@@ -842,7 +855,11 @@ __global__ __launch_bounds__(1024) void g_cols_fwd(const void* __restrict__ iq, 
                },
                [&](int idx, float2 v) { x[TileFwd::pos(idx)] = v; });
     __syncthreads();
-    lds_dif<kColLogT>(x, l1, twl, tid, nthr);
+    {
+        const TileFwd io{x};
+        fft_dif<kColLogT>(x, l1, twl, tid, nthr, SrcZeroTail<TileFwd>{io, nz}, io);
+        __syncthreads();
+    }
     float2* o = out + (long)blockIdx.y * L;
     batched<8>(tid, L1 << kColLogT, nthr, [&](int idx) -> float2 { return x[TileFwd::pos(idx)]; },
                [&](int idx, float2 v) {
@@ -889,10 +906,12 @@ __global__ __launch_bounds__(1024) void g_cols_inv(const float2* __restrict__ in
         make_src([&](int E) -> float2 { return src[(long)(E >> kColLogT) * L2 + c0 + (E & (kColT - 1))]; }),
         make_dst([&](int E0, int off, float2 e) {
             const int E = E0 + off;
-            const long m = (long)(E >> kColLogT) * L2 + c0 + (E & (kColT - 1));
-            const int k = full_index((int)m, N);
             const float v = e.x * e.x + e.y * e.y;
-            if (k >= 0 && (v > best || (v == best && k < bk))) { best = v; bk = k; }
+            if (v >= best) {                      // (rare after the first few elements: the index arithmetic stays off the common path)
+                const int m = ((E >> kColLogT) << l2) + c0 + (E & (kColT - 1));
+                const int k = full_index(m, N);
+                if (k >= 0 && (v > best || k < bk)) { best = v; bk = k; }
+            }
             x[TileInv::pos(E0) + TileInv::pos(off)] = make_float2(v, 0.0f);
         }));
     __syncthreads();
