@@ -843,7 +843,7 @@ __global__ __launch_bounds__(1024) void g_cols_fwd(const void* __restrict__ iq, 
     const int nz = (L1 >> 1) << kColLogT;                     // only the rows n1 < L1/2 are non-zero: the others are
     batched<8>(tid, nz, nthr,                                 // neither filled nor read (first pass below)
                [&](int idx) -> float2 {
-                   const long n = (long)(idx >> kColLogT) * L2 + c0 + (idx & (kColT - 1));
+                   const int n = ((idx >> kColLogT) << l2) + c0 + (idx & (kColT - 1));   // < N: 32-bit
                    float2 v;
                    if constexpr (U8) {
                        const uchar2 b8 = reinterpret_cast<const uchar2*>(iq)[item * N + n];
@@ -867,7 +867,7 @@ __global__ __launch_bounds__(1024) void g_cols_fwd(const void* __restrict__ iq, 
                    const int k1 = brev(pos, l1);
                    const float2* tc = tab + c * (na + nb + kTabPad);
                    const float2 w = g_cmul(tc[k1 & (na - 1)], tc[na + (k1 >> a)]);
-                   o[(long)pos * L2 + c0 + c] = g_cmul(v, w);
+                   o[(pos << l2) + c0 + c] = g_cmul(v, w);             // index < L <= 2^23
                });
 }
 // inverse: in[k1'][n2] (after the inverse row pass and its twiddle) -> this tile of r[n1][n2] in LDS only: the
@@ -903,7 +903,7 @@ __global__ __launch_bounds__(1024) void g_cols_inv(const float2* __restrict__ in
     // |r|^2 in the buffer, for the taps and the halo
     fft_dit_inv<kColLogT>(
         x, l1, twl, tid, nthr,
-        make_src([&](int E) -> float2 { return src[(long)(E >> kColLogT) * L2 + c0 + (E & (kColT - 1))]; }),
+        make_src([&](int E) -> float2 { return src[((E >> kColLogT) << l2) + c0 + (E & (kColT - 1))]; }),
         make_dst([&](int E0, int off, float2 e) {
             const int E = E0 + off;
             const float v = e.x * e.x + e.y * e.y;
