@@ -621,3 +621,28 @@ def test_fused_row_kernel_by_row_length(xc, N, B, monkeypatch):
     with xc.XcorrEngine(B, N, W) as eng:
         ui, uf, up = eng.correlate(iq)
     assert np.array_equal(ui, li) and np.all(np.abs(uf - lf) <= TOL) and np.allclose(up, pk, rtol=1e-5)
+
+
+@pytest.mark.parametrize("case", range(12))
+def test_seeded_random_shapes_and_pair_lists(xc, case):
+    """Seeded sweep over (buoys, window length, windows, pair list): every kernel family gets shapes nobody
+    hand-picked -- odd buoy counts, custom lists with reversed and repeated pairs, single windows -- against the
+    literal oracle."""
+    rng = np.random.default_rng(4200 + case)
+    logn = int(rng.integers(4, 17))                       # N = 16 .. 65536
+    N = 1 << logn
+    B = int(rng.integers(2, 10))
+    W = int(rng.integers(1, 4)) if logn >= 13 else int(rng.integers(1, 9))
+    iq, _ = rm.synth.make_windows(W, B, N, 2.4e6, seed=4300 + case)
+    pairs = None
+    if case % 2:                                          # custom list: random ordered pairs, i != j, repeats allowed
+        P = int(rng.integers(1, 8))
+        a = rng.integers(0, B, size=P)
+        b = (a + rng.integers(1, B, size=P)) % B
+        pairs = np.stack([a, b], axis=1).astype(np.int32)
+    ri, rf, rp = orc.xcorr_batch_literal(iq, pairs)
+    plist = orc.pair_list(B) if pairs is None else pairs
+    margin = np.array([[orc.peak_margin(iq[w, i], iq[w, j]) for (i, j) in plist] for w in range(W)])
+    with xc.XcorrEngine(B, N, W) as eng:
+        li, lf, pk = eng.correlate(iq, pairs) if pairs is not None else eng.correlate(iq)
+    _assert_parity(li, lf, pk, ri, rf, rp, margin)
