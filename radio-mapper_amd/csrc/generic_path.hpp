@@ -35,6 +35,9 @@
 namespace rmx {
 namespace gen {
 
+#ifndef RMX_PROD_BATCH
+#define RMX_PROD_BATCH 4
+#endif
 constexpr int kGThreads = 256;
 // threads per row of the row kernels: two threads per radix-16 group (the passes leave half of them idle, the
 // streaming loops use all: measured better than one thread per group on the 2048-point rows of cfg2)
@@ -572,7 +575,7 @@ __global__ __launch_bounds__(kGThreads) void g_rows(float2* __restrict__ data, c
             const GPair pr = pairs[q];
             const float2* xi = spec + (((long)wl * n_buoys + pr.i) * n_rows + rib) * R;
             const float2* xj = spec_j + (((long)wl * n_buoys + pr.j) * n_rows + rib) * R;
-            batched<4>(tid, R, tpr, [&](int n) -> float4 { const float2 u = xj[n], v = xi[n]; return make_float4(u.x, u.y, v.x, v.y); },
+            batched<RMX_PROD_BATCH>(tid, R, tpr, [&](int n) -> float4 { const float2 u = xj[n], v = xi[n]; return make_float4(u.x, u.y, v.x, v.y); },
                        [&](int n, float4 v) { x[lp(n)] = g_cmulc(make_float2(v.x, v.y), make_float2(v.z, v.w)); });
         }
         __syncthreads();

@@ -610,7 +610,7 @@ def test_fused_row_kernel_by_row_length(xc, N, B, monkeypatch):
     iq, _ = rm.synth.make_windows(W, B, N, 2.4e6, seed=900 + B + N % 991)
     ri, rf, rp = orc.xcorr_batch_literal(iq)
     margin = np.array([[orc.peak_margin(iq[w, i], iq[w, j]) for (i, j) in orc.pair_list(B)] for w in range(W)])
-    custom = np.array([(B - 1, 0), (0, 1)], np.int32)
+    custom = np.array([(B - 1, 0), (0, 1), (1, 1)], np.int32)      # reversed, plain, autocorrelation
     with xc.XcorrEngine(B, N, W) as eng:
         li, lf, pk = eng.correlate(iq)
         ci, cf, cp = eng.correlate(iq, custom)
