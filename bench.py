@@ -454,7 +454,7 @@ def main():
             kernel = ("rmx_caf_batch kernel sequence (un-rotated spectra once; per Doppler bin: de-rotated forward "
                       "g_cols_fwd + g_rows, g_rows(product, inverse), g_cols_inv, g_final, k_caf_select)" if caf else
                       ("four-step sequence g_cols_fwd + g_rows_fused (forward rows, products, inverse rows) + g_cols_inv "
-                       "+ g_final" if B <= 4 else
+                       "+ g_final" if B <= 4 and W >= 4 else
                        "four-step sequence g_cols_fwd + g_rows + g_rows(product, inverse) + g_cols_inv + g_final"))
             launch_ms = region_ms / steps
             isolated_launch_ms = None

@@ -1174,6 +1174,7 @@ struct rmx_ctx {
     bool generic = false;
     int g_logL = 0, g_logL1 = 0, g_logL2 = 0, g_lo_bits = 0, g_chunk = 0;
     bool g_fused = false;      // four-step: both row passes in g_rows_fused (n_buoys <= 4, plain batches)
+    bool g_fused_always = false;
     int g_fused_wgs = 0;       // its persistent grid
     const void* g_fused_fn = nullptr;
     const void* g_cols_inv_fn = nullptr;
@@ -1518,7 +1519,10 @@ static int generic_init(rmx_ctx* c) {
         RMX_HIP(c, hipFuncSetAttribute(c->g_rows_inv_fn, hipFuncAttributeMaxDynamicSharedMemorySize, rows_lds));
         // both row passes in one kernel when the buoys' spectra rows fit the register file (generic_path.hpp)
         c->g_fused = c->n_buoys <= 4 && c->g_logL2 >= 9 && c->g_logL2 <= 12;
-        if (const char* e = getenv("RMX_FUSED")) c->g_fused = c->g_fused && atoi(e) != 0;
+        if (const char* e = getenv("RMX_FUSED")) {      // 0: never, 2: also for batches too small to fill the chip (tests)
+            c->g_fused = c->g_fused && atoi(e) != 0;
+            c->g_fused_always = atoi(e) == 2;
+        }
         if (c->g_fused) {
             const int flds = (int)gen_fused_lds(1 << c->g_logL2);
             const void* fn = fused_fn(c->n_buoys, c->g_logL2);
@@ -1710,7 +1714,10 @@ static int generic_batch(rmx_ctx* c, const void* d_iq, int n_windows, int n_pair
     if (rc) return rc;
     for (int w0 = 0; w0 < n_windows; w0 += c->g_chunk) {
         const int wc = n_windows - w0 < c->g_chunk ? n_windows - w0 : c->g_chunk;
-        const bool fused = c->g_fused && (1L << c->g_logL) > kGenSmallMaxL;
+        // the fused row kernel when its (window, row block) units fill the chip at least twice: below that (cfg1's single
+        // window: 128 workgroups) its long serial chain per unit loses to the two-kernel passes' wider grids (57 vs 47 us)
+        const long fused_blocks = c->g_fused ? (long)wc * (1L << c->g_logL1) / (gen::kGThreads / ((1 << c->g_logL2) >> 4)) : 0;
+        const bool fused = c->g_fused && (1L << c->g_logL) > kGenSmallMaxL && (fused_blocks >= 2L * c->n_cus || c->g_fused_always);
         rc = generic_forward(c, d_iq, w0, wc, u8, nullptr, fused);
         if (rc) return rc;
         rc = generic_pairs(c, w0, wc, n_pairs, d_lag, d_frac, d_peak, false, fused);

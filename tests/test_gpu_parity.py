@@ -611,6 +611,7 @@ def test_fused_row_kernel_by_row_length(xc, N, B, monkeypatch):
     ri, rf, rp = orc.xcorr_batch_literal(iq)
     margin = np.array([[orc.peak_margin(iq[w, i], iq[w, j]) for (i, j) in orc.pair_list(B)] for w in range(W)])
     custom = np.array([(B - 1, 0), (0, 1), (1, 1)], np.int32)      # reversed, plain, autocorrelation
+    monkeypatch.setenv("RMX_FUSED", "2")       # (two windows would not fill the chip: the engine would pick the two-kernel passes)
     with xc.XcorrEngine(B, N, W) as eng:
         li, lf, pk = eng.correlate(iq)
         ci, cf, cp = eng.correlate(iq, custom)
