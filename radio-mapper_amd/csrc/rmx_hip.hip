@@ -1484,6 +1484,7 @@ static int generic_init(rmx_ctx* c) {
         // columns a little shorter than rows (measured: 512 x 4096 beats 1024 x 2048 at L = 2^21, 256 x 2048 beats
         // 512 x 1024 at 2^19), rows at most 8192 (64 KiB of LDS)
         c->g_logL1 = (c->g_logL - 3) / 2;
+        if (c->g_logL == 18) c->g_logL1 = 8;   // (measured with this round's kernels: 256 x 1024 beats 128 x 2048 by 5 %)
         if (c->g_logL1 < c->g_logL - 13) c->g_logL1 = c->g_logL - 13;
         if (c->g_logL1 > 10) c->g_logL1 = 10;
         if (const char* e = getenv("RMX_LOGL1")) { const int v = atoi(e); if (v >= 4 && v <= 10 && c->g_logL - v <= 13 && c->g_logL - v >= 4) c->g_logL1 = v; }
