@@ -75,15 +75,25 @@ __device__ __forceinline__ float lds_select(const float* p, int N, int rank, uns
             if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
         }
         __syncthreads();
-        if (tid == 0) {
-            unsigned acc = 0;
-            int b = 0;
-            for (; b < 256; ++b) {
-                if (acc + hist[b] > (unsigned)r) break;
-                acc += hist[b];
+        if (tid < 64) {     // first bucket whose cumulative count exceeds r: four buckets per lane, one wave scan
+            const unsigned h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+            const unsigned tot = h0 + h1 + h2 + h3;
+            unsigned incl = tot;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned o = __shfl_up(incl, off, 64);
+                if (tid >= off) incl += o;
             }
-            bc[0] = (unsigned)b;
-            bc[1] = acc;
+            const unsigned excl = incl - tot;
+            if (excl <= (unsigned)r && (unsigned)r < incl) {
+                unsigned acc = excl;
+                int b = 4 * tid;
+                if (acc + h0 <= (unsigned)r) { acc += h0; ++b;
+                    if (acc + h1 <= (unsigned)r) { acc += h1; ++b;
+                        if (acc + h2 <= (unsigned)r) { acc += h2; ++b; } } }
+                bc[0] = (unsigned)b;
+                bc[1] = acc;
+            }
         }
         __syncthreads();
         prefix |= bc[0] << shift;
@@ -155,6 +165,10 @@ __global__ __launch_bounds__(1024) void d_peaks(const float* __restrict__ pdb, i
                 if (top) st[i] = 4;
             }
             __syncthreads();
+            // neighbours of this round's keeps are removed; a keep stays marked 4 until the rounds are over (no undecided
+            // candidate is left within reach of one, so later rounds never meet it) -- one loop and two barriers fewer
+            // per round than promoting 4 -> 2 here
+            bool undecided = false;
             for (int c = tid; c < ncand; c += nthr) {
                 const int i = cand[c];
                 if (st[i] != 1) continue;
@@ -163,25 +177,48 @@ __global__ __launch_bounds__(1024) void d_peaks(const float* __restrict__ pdb, i
                 for (int j = lo; j <= hi; ++j)
                     if (st[j] == 4) { hit = true; break; }
                 if (hit) st[i] = 3;
+                else undecided = true;
             }
-            __syncthreads();
-            for (int c = tid; c < ncand; c += nthr) {
-                const int i = cand[c];
-                if (st[i] == 4) st[i] = 2;
-                else if (st[i] == 1) bc[3] = 1;        // benign race: any writer writes 1
-            }
+            if (undecided) bc[3] = 1;                  // benign race: any writer writes 1
             __syncthreads();
             const bool more = bc[3] != 0;
             __syncthreads();
             if (!more) break;
         }
+        for (int c = tid; c < ncand; c += nthr)
+            if (st[cand[c]] == 4) st[cand[c]] = 2;
+        __syncthreads();
     } else {
         for (int c = tid; c < ncand; c += nthr) st[cand[c]] = 2;
         __syncthreads();
     }
     // noise floor = median (mean of the two middle values for even N, as np.median)
-    const float m_hi = lds_select(p, N, N / 2, hist, bc, tid, nthr);
-    const float m_lo = (N & 1) ? m_hi : lds_select(p, N, N / 2 - 1, hist, bc, tid, nthr);
+    // (even N: the upper middle value is the lower one again, or the smallest value above it -- one counting pass
+    // instead of a second four-pass select)
+    float m_lo, m_hi;
+    if (N & 1) {
+        m_lo = m_hi = lds_select(p, N, N / 2, hist, bc, tid, nthr);
+    } else {
+        m_lo = lds_select(p, N, N / 2 - 1, hist, bc, tid, nthr);
+        const unsigned klo = f32_key(m_lo);
+        if (tid == 0) { bc[5] = 0; bc[6] = 0xffffffffu; }
+        __syncthreads();
+        unsigned le = 0, nxt = 0xffffffffu;
+        for (int i = tid; i < N; i += nthr) {
+            const unsigned k = f32_key(p[i]);
+            if (k <= klo) ++le;
+            else if (k < nxt) nxt = k;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            le += __shfl_xor(le, off, 64);
+            const unsigned o = __shfl_xor(nxt, off, 64);
+            nxt = o < nxt ? o : nxt;
+        }
+        if ((tid & 63) == 0) { atomicAdd(&bc[5], le); atomicMin(&bc[6], nxt); }
+        __syncthreads();
+        m_hi = bc[5] > (unsigned)(N / 2) ? m_lo : key_f32(bc[6]);
+    }
     const float floor_v = (m_lo + m_hi) * 0.5f;
     // ordered compaction: every thread owns a contiguous run of bins
     const int per = (N + nthr - 1) / nthr;
@@ -197,15 +234,29 @@ __global__ __launch_bounds__(1024) void d_peaks(const float* __restrict__ pdb, i
     int mine = 0;
     float s_, c_;
     for (int k = b0; k < b1; ++k) mine += passes(k, s_, c_) ? 1 : 0;
-    scan[tid] = (unsigned)mine;
+    // exclusive prefix sum over the threads: inside each wave by shuffles, across the (at most 16) waves by one wave
+    // (a serial loop of thread 0 over 1024 LDS words was 60 us of this kernel's 280 per window)
+    unsigned incl = (unsigned)mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned o = __shfl_up(incl, off, 64);
+        if ((tid & 63) >= off) incl += o;
+    }
+    if ((tid & 63) == 63) scan[tid >> 6] = incl;   // wave totals
     __syncthreads();
-    if (tid == 0) {
-        unsigned acc = 0;
-        for (int i = 0; i < nthr; ++i) { const unsigned v = scan[i]; scan[i] = acc; acc += v; }
-        bc[4] = acc;
+    if (tid < 64) {
+        const int nw = (nthr + 63) >> 6;
+        unsigned t = tid < nw ? scan[tid] : 0u, ti = t;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned o = __shfl_up(ti, off, 64);
+            if (tid >= off) ti += o;
+        }
+        if (tid < nw) scan[64 + tid] = ti - t;      // exclusive offset of wave tid
+        if (tid == nw - 1) bc[4] = ti;
     }
     __syncthreads();
-    int at = (int)scan[tid];
+    int at = (int)(scan[64 + (tid >> 6)] + incl - (unsigned)mine);
     const long ob = w * max_peaks;
     for (int k = b0; k < b1; ++k) {
         float snr, conf;

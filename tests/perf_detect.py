@@ -26,7 +26,7 @@ eng.set_stream(torch.cuda.current_stream().cuda_stream)
 lib = xcorr.load_library()
 p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
 def call():
-    assert lib.rmx_detect_batch(eng._ctx, p(xd), W, N, -70.0, 10, 10e3 * N / 2.4e6, 0.3, MP, p(cnt), p(bins), p(pw), p(snr),
+    assert lib.rmx_detect_batch(eng._ctx, p(xd), W, N, -70.0, int(os.environ.get("DET_DIST", "10")), 10e3 * N / 2.4e6, 0.3, MP, p(cnt), p(bins), p(pw), p(snr),
                                 p(cf), p(fl), 3) == 0
 call(); torch.cuda.synchronize()
 ts = []
