@@ -149,6 +149,7 @@ __global__ __launch_bounds__(1024) void d_peaks(const float* __restrict__ pdb, i
     const int ncand = (int)bc[2];
     // distance filter in rounds
     if (dist > 1) {
+        const int span = 2 * (dist - 1) + 1;
         for (;;) {
             if (tid == 0) bc[3] = 0;
             __syncthreads();
@@ -156,11 +157,25 @@ __global__ __launch_bounds__(1024) void d_peaks(const float* __restrict__ pdb, i
                 const int i = cand[c];
                 if (st[i] != 1) continue;
                 const float v = p[i];
-                const int lo = i - (dist - 1) < 0 ? 0 : i - (dist - 1), hi = i + (dist - 1) > N - 1 ? N - 1 : i + (dist - 1);
+                // the 2 dist - 1 neighbours in batches of eight independent reads (a loop with an early exit is a chain
+                // of dependent LDS latencies: 32 us per round at N = 16 384)
                 bool top = true;
-                for (int j = lo; j <= hi; ++j) {
-                    const unsigned char s = st[j];
-                    if ((s == 1 || s == 4) && j != i && (p[j] > v || (p[j] == v && j > i))) { top = false; break; }
+                for (int k0 = 0; k0 < span; k0 += 8) {
+                    unsigned char s8[8];
+                    float p8[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int j = i - (dist - 1) + k0 + u;
+                        const int jc = (k0 + u < span && j >= 0 && j < N) ? j : i;     // out of range: the candidate itself (ignored below)
+                        s8[u] = st[jc];
+                        p8[u] = p[jc];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int j = i - (dist - 1) + k0 + u;
+                        const bool in = k0 + u < span && j >= 0 && j < N && j != i;
+                        if (in && (s8[u] == 1 || s8[u] == 4) && (p8[u] > v || (p8[u] == v && j > i))) top = false;
+                    }
                 }
                 if (top) st[i] = 4;
             }
@@ -172,10 +187,17 @@ __global__ __launch_bounds__(1024) void d_peaks(const float* __restrict__ pdb, i
             for (int c = tid; c < ncand; c += nthr) {
                 const int i = cand[c];
                 if (st[i] != 1) continue;
-                const int lo = i - (dist - 1) < 0 ? 0 : i - (dist - 1), hi = i + (dist - 1) > N - 1 ? N - 1 : i + (dist - 1);
                 bool hit = false;
-                for (int j = lo; j <= hi; ++j)
-                    if (st[j] == 4) { hit = true; break; }
+                for (int k0 = 0; k0 < span; k0 += 8) {
+                    unsigned char s8[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int j = i - (dist - 1) + k0 + u;
+                        s8[u] = st[(k0 + u < span && j >= 0 && j < N) ? j : i];        // (the candidate itself is 1, never 4)
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) hit = hit || s8[u] == 4;
+                }
                 if (hit) st[i] = 3;
                 else undecided = true;
             }
