@@ -702,7 +702,7 @@ __device__ __forceinline__ void constexpr_pair(int ij, const float2 (&S)[NB][16]
 #pragma unroll
     for (int k = 0; k < 16; ++k) v[k] = g_cmulc(S[j][k], S[i][k]);
 }
-template <int NB, int LOGR>
+template <int NB, int LOGR, bool DEF = false>      // DEF: the default plan (all pairs i < j in order), pair loop unrolled
 __global__ __launch_bounds__(kGThreads, 2) void g_rows_fused(const float2* __restrict__ cols, float2* __restrict__ prod,
                                                           const float2* __restrict__ tw, int n_rows, int row_bits,
                                                           long Ltot, int lo_bits, const float2* __restrict__ thi,
@@ -758,19 +758,8 @@ __global__ __launch_bounds__(kGThreads, 2) void g_rows_fused(const float2* __res
             __builtin_amdgcn_sched_barrier(0);    // (the last butterfly is not to be interleaved with the next first pass)
             __syncthreads();                      // the next transform's first pass overwrites x
         }
-        for (int q = 0; q < n_pairs; ++q) {
-            const GPair pr = pairs[q];
-            float2 v[16];
-            // the pair's two spectra: register arrays cannot be indexed at run time, so one (workgroup-uniform)
-            // branch per ordered pair
-            const int code = pr.i * NB + pr.j;
-            constexpr_pair<NB>(0, S, v);          // (defined on every path: no value carried around the pair loop)
-#pragma unroll
-            for (int ij = 1; ij < NB * NB; ++ij)
-                if (code == ij) {
-                    asm volatile("" ::: "memory");    // keeps the branch: hipcc otherwise computes all NB^2 products and selects
-                    constexpr_pair<NB>(ij, S, v);
-                }
+        // inverse of the product in v (input k of the first butterfly) and the twiddled store to pair slot q
+        auto finish = [&](float2 (&v)[16], int q) {
             int tl = tid;
             asm volatile("" : "+v"(tl));
             fft_dit_inv_from_regs<LOGR>(x, twl, tl, v);
@@ -785,6 +774,35 @@ __global__ __launch_bounds__(kGThreads, 2) void g_rows_fused(const float2* __res
                 }
             }
             __syncthreads();                      // x (and, behind the last pair, t1) are rewritten
+        };
+        if constexpr (DEF) {
+            // the default plan, (i, j) with i < j, i-major: the pair loop unrolled, every product's registers known at
+            // compile time (no branch chain; a buoy's spectrum registers are dead after its last pair)
+            int q = 0;
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+#pragma unroll
+                for (int j = i + 1; j < NB; ++j) {
+                    float2 v[16];
+                    constexpr_pair<NB>(i * NB + j, S, v);
+                    finish(v, q++);
+                }
+        } else {
+            for (int q = 0; q < n_pairs; ++q) {
+                const GPair pr = pairs[q];
+                float2 v[16];
+                // the pair's two spectra: register arrays cannot be indexed at run time, so one (workgroup-uniform)
+                // branch per ordered pair
+                const int code = pr.i * NB + pr.j;
+                constexpr_pair<NB>(0, S, v);      // (defined on every path: no value carried around the pair loop)
+#pragma unroll
+                for (int ij = 1; ij < NB * NB; ++ij)
+                    if (code == ij) {
+                        asm volatile("" ::: "memory");    // keeps the branch: hipcc otherwise computes all NB^2 products and selects
+                        constexpr_pair<NB>(ij, S, v);
+                    }
+                finish(v, q);
+            }
         }
     }
 }

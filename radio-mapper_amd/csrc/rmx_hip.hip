@@ -1177,6 +1177,8 @@ struct rmx_ctx {
     bool g_fused_always = false;
     int g_fused_wgs = 0;       // its persistent grid
     const void* g_fused_fn = nullptr;
+    const void* g_fused_def_fn = nullptr;  // the same for the default plan (pair loop unrolled)
+    int g_fused_def_wgs = 0;
     const void* g_cols_inv_fn = nullptr;
     const void* g_cols_fwd_fn[2] = {nullptr, nullptr};   // [u8]
     const void* g_rows_inv_fn = nullptr;
@@ -1435,10 +1437,11 @@ static const void* rows_inv_fn(int logR, int tpr) {       // the inverse row ker
         default: return (const void*)g_rows<false, true, true>;
     }
 }
-static const void* fused_fn(int nb, int logR) {         // g_rows_fused<n_buoys, log2 row length>
-#define RMX_FF(NB) (logR == 9 ? (const void*)gen::g_rows_fused<NB, 9> : logR == 10 ? (const void*)gen::g_rows_fused<NB, 10> : \
-                    logR == 11 ? (const void*)gen::g_rows_fused<NB, 11> : (const void*)gen::g_rows_fused<NB, 12>)
-    return nb == 2 ? RMX_FF(2) : nb == 3 ? RMX_FF(3) : RMX_FF(4);
+static const void* fused_fn(int nb, int logR, bool def) {   // g_rows_fused<n_buoys, log2 row length, default plan>
+#define RMX_FF(NB, D) (logR == 9 ? (const void*)gen::g_rows_fused<NB, 9, D> : logR == 10 ? (const void*)gen::g_rows_fused<NB, 10, D> : \
+                       logR == 11 ? (const void*)gen::g_rows_fused<NB, 11, D> : (const void*)gen::g_rows_fused<NB, 12, D>)
+    if (def) return nb == 2 ? RMX_FF(2, true) : nb == 3 ? RMX_FF(3, true) : RMX_FF(4, true);
+    return nb == 2 ? RMX_FF(2, false) : nb == 3 ? RMX_FF(3, false) : RMX_FF(4, false);
 #undef RMX_FF
 }
 static size_t gen_fused_lds(int R) {                    // g_rows_fused: R/16 threads per row
@@ -1526,8 +1529,16 @@ static int generic_init(rmx_ctx* c) {
         }
         if (c->g_fused) {
             const int flds = (int)gen_fused_lds(1 << c->g_logL2);
-            const void* fn = fused_fn(c->n_buoys, c->g_logL2);
+            const void* fn = fused_fn(c->n_buoys, c->g_logL2, false);
             c->g_fused_fn = fn;
+            c->g_fused_def_fn = fused_fn(c->n_buoys, c->g_logL2, true);
+            if (const char* e = getenv("RMX_FUSED_DEF")) { if (atoi(e) == 0) c->g_fused_def_fn = nullptr; }
+            if (c->g_fused_def_fn) {
+                RMX_HIP(c, hipFuncSetAttribute(c->g_fused_def_fn, hipFuncAttributeMaxDynamicSharedMemorySize, flds));
+                int pc = 0;
+                RMX_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, c->g_fused_def_fn, kGThreads, (size_t)flds));
+                c->g_fused_def_wgs = (pc > 0 ? pc : 1) * c->n_cus;
+            }
             RMX_HIP(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, flds));
             int per_cu = 0;
             RMX_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kGThreads, (size_t)flds));
@@ -1672,7 +1683,9 @@ static int generic_pairs(rmx_ctx* c, int w0, int wc, int n_pairs, int* d_lag, fl
         const long units = (long)wc * L1;
         const int upw = kGThreads / (L2 >> 4 > 0 ? L2 >> 4 : 1);
         const long blocks = (units + upw - 1) / upw;
-        const dim3 grid((unsigned)(blocks < c->g_fused_wgs ? blocks : c->g_fused_wgs));
+        const bool def_plan = c->g_fused_def_fn && c->plan_all_pairs && n_pairs == B * (B - 1) / 2;
+        const long wgs = def_plan ? c->g_fused_def_wgs : c->g_fused_wgs;
+        const dim3 grid((unsigned)(blocks < wgs ? blocks : wgs));
         const float fs = std::ldexp(1.0f, -(logL / 2));
         const float2* colsp = c->g_spec;
         float2* prodp = c->g_prod;
@@ -1682,7 +1695,7 @@ static int generic_pairs(rmx_ctx* c, int w0, int wc, int n_pairs, int* d_lag, fl
         long a_L = L, a_units = units;
         float a_scale = fs * fs;
         void* args[] = {&colsp, &prodp, &twp, &a_L1, &a_l1, &a_L, &a_lo, &thip, &tlop, &a_scale, &a_units, &pp, &a_np};
-        RMX_HIP(c, hipLaunchKernel(c->g_fused_fn, grid, dim3(kGThreads), args, gen_fused_lds(L2), st));
+        RMX_HIP(c, hipLaunchKernel(def_plan ? c->g_fused_def_fn : c->g_fused_fn, grid, dim3(kGThreads), args, gen_fused_lds(L2), st));
     } else
     {
         float2* a_data = c->g_prod;
