@@ -861,24 +861,34 @@ __global__ __launch_bounds__(1024) void g_cols_fwd(const void* __restrict__ iq, 
     __syncthreads();
     // (first pass from HBM / last pass to HBM measured slower here: 2.0 vs 1.58 ms on cfg2 -- the sink's table
     // lookups on top of a radix-16 pass spill)
-    const int nz = (L1 >> 1) << kColLogT;                     // only the rows n1 < L1/2 are non-zero: the others are
-    batched<8>(tid, nz, nthr,                                 // neither filled nor read (first pass below)
-               [&](int idx) -> float2 {
-                   const int n = ((idx >> kColLogT) << l2) + c0 + (idx & (kColT - 1));   // < N: 32-bit
-                   float2 v;
-                   if constexpr (U8) {
-                       const uchar2 b8 = reinterpret_cast<const uchar2*>(iq)[item * N + n];
-                       v = make_float2((float)b8.x - 127.5f, (float)b8.y - 127.5f);
-                   } else {
-                       v = reinterpret_cast<const float2*>(iq)[item * N + n];
-                   }
-                   return rot ? rot_mul(v, rot[n]) : v;
-               },
-               [&](int idx, float2 v) { x[TileFwd::pos(idx)] = v; });
+    const int nz = (L1 >> 1) << kColLogT;                     // only the rows n1 < L1/2 are non-zero
+    auto sample = [&](int idx) -> float2 {                    // tile element idx = (row << LOGT) | column, from HBM
+        const int n = ((idx >> kColLogT) << l2) + c0 + (idx & (kColT - 1));   // < N: 32-bit
+        float2 v;
+        if constexpr (U8) {
+            const uchar2 b8 = reinterpret_cast<const uchar2*>(iq)[item * N + n];
+            v = make_float2((float)b8.x - 127.5f, (float)b8.y - 127.5f);
+        } else {
+            v = reinterpret_cast<const float2*>(iq)[item * N + n];
+        }
+        return rot ? rot_mul(v, rot[n]) : v;
+    };
+    // short columns (L1 <= 64: N = 8192 0.49 -> 0.46 ms) hand the first pass its inputs straight from HBM; longer ones
+    // stage the tile in LDS first (cfg2 3.60 vs 3.66 ms, 8 buoys x 2^18 0.91 vs 0.94 ms)
+    if constexpr (!(L1C > 0 && L1C <= 6)) {
+    batched<8>(tid, nz, nthr, sample, [&](int idx, float2 v) { x[TileFwd::pos(idx)] = v; });
     __syncthreads();
     {
         const TileFwd io{x};
         fft_dif<kColLogT>(x, l1, twl, tid, nthr, SrcZeroTail<TileFwd>{io, nz}, io);
+        __syncthreads();
+    }
+    } else {   // the first pass reads its (eight non-zero of sixteen) inputs straight from HBM: rows L1/16 apart of one
+        // column per thread, consecutive threads on consecutive columns -- the same 128-byte row segments a tile load
+        // fetches, without the tile's trip through LDS
+        const TileFwd io{x};
+        const auto hbm = make_src(sample);
+        fft_dif<kColLogT>(x, l1, twl, tid, nthr, SrcZeroTail<decltype(hbm)>{hbm, nz}, io);
         __syncthreads();
     }
     float2* o = out + (long)blockIdx.y * L;
