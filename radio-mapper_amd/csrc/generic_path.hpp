@@ -892,6 +892,23 @@ __global__ __launch_bounds__(1024) void g_cols_fwd(const void* __restrict__ iq, 
         __syncthreads();
     }
     float2* o = out + (long)blockIdx.y * L;
+    if constexpr (L1C >= 8 && kColLogT == 4) {
+        // compile-time column length: thread tid stores elements tid + k nthr, k < 16 -- always column c = tid & 15, rows
+        // plo + k 2^pb.  The bit-reversed row index k1 then splits into bitrev(k) (its low four bits: the T1 entry, an
+        // immediate offset) and bitrev(plo) (the T2 entry: one read per thread instead of one per element)
+        constexpr int pb = L1C - 4;
+        static_assert((cols_threads(L1C, 4) >> 4) == (1 << pb) && (L1C >> 1) == 4, "16 elements per thread, a = 4");
+        const int c = tid & 15, plo = tid >> 4;
+        const float2* tc = tab + c * (na + nb + kTabPad);
+        const float2 t2v = tc[na + brev(plo, pb)];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const float2 v = x[TileFwd::pos(tid + k * nthr)];
+            const float2 w = g_cmul(tc[brev_m<4>(k)], t2v);
+            o[((plo + (k << pb)) << l2) + c0 + c] = g_cmul(v, w);
+        }
+        return;
+    }
     batched<8>(tid, L1 << kColLogT, nthr, [&](int idx) -> float2 { return x[TileFwd::pos(idx)]; },
                [&](int idx, float2 v) {
                    const int c = idx & (kColT - 1), pos = idx >> kColLogT;
