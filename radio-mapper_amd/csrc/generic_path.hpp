@@ -960,7 +960,7 @@ __global__ __launch_bounds__(1024) void g_cols_inv(const float2* __restrict__ in
                 const int k = full_index(m, N);
                 if (k >= 0 && (v > best || k < bk)) { best = v; bk = k; }
             }
-            x[TileInv::pos(E0) + TileInv::pos(off)] = make_float2(v, 0.0f);
+            x[TileInv::pos(E0) + TileInv::pos(off)].x = v;        // (4-byte store: only .x is read back, by the halo and the taps)
         }));
     __syncthreads();
     // halo: |r|^2 of columns c0 and c0 + T - 1, all rows: [slot][tile][2][L1]
