@@ -858,7 +858,9 @@ __global__ __launch_bounds__(1024) void g_cols_fwd(const void* __restrict__ iq, 
         const long ee = e < na ? (long)e : ((long)(e - na) << a);
         tab[c * (na + nb + kTabPad) + e] = big_tw((long)(c0 + c) * ee, lo_bits, thi, tlo);
     }
-    __syncthreads();
+    // (no barrier here on the staged path: the tile's loads below go out behind the tables' and both latencies overlap;
+    // the barrier behind the staging covers the tables too)
+    if constexpr (L1C > 0 && L1C <= 6) __syncthreads();
     // (first pass from HBM / last pass to HBM measured slower here: 2.0 vs 1.58 ms on cfg2 -- the sink's table
     // lookups on top of a radix-16 pass spill)
     const int nz = (L1 >> 1) << kColLogT;                     // only the rows n1 < L1/2 are non-zero
