@@ -214,13 +214,19 @@ __device__ __forceinline__ DstFn<F> make_dst(F f) { return DstFn<F>{f}; }
 // Where a pass takes W_R^(l k 2^(logR-b)) from (TWM): 0 = the half table tw[e], e < R/2, with the sign fix-up;
 // 2 = this pass's own table tw[(k-1) q + l] (consecutive lanes read consecutive entries: the strided reads of
 // mode 0 are 2..16-way LDS bank conflicts -- SQ_LDS_BANK_CONFLICT was half of the LDS cycles of g_rows_fused)
-template <int TWM>
-__device__ __forceinline__ float2 pass_tw(const float2* __restrict__ tw, int es, int l, int k, int q, int half) {
-    if constexpr (TWM == 2) return tw[(k - 1) * q + l];
+// 3 = registers: tw.w[k-1], the thread's own 2^M - 1 twiddles of this pass (a pass with one butterfly per thread:
+// they are the same for every transform the thread ever does)
+struct TwRegs {
+    float2 w[15];
+};
+template <int TWM, class TwT>
+__device__ __forceinline__ float2 pass_tw(const TwT& tw, int es, int l, int k, int q, int half) {
+    if constexpr (TWM == 3) return tw.w[k - 1];
+    else if constexpr (TWM == 2) return tw[(k - 1) * q + l];
     else return tw_full(tw, es * k, half);
 }
-template <int M, int LOGT, int TWM = 0, class Src, class Dst>
-__device__ __forceinline__ void dif_pass(int logR, int b, const float2* __restrict__ tw, int tid, int nthr, const Src& src,
+template <int M, int LOGT, int TWM = 0, class Src, class Dst, class TwT = const float2*>
+__device__ __forceinline__ void dif_pass(int logR, int b, const TwT& tw, int tid, int nthr, const Src& src,
                                          const Dst& dst) {
     constexpr int RAD = 1 << M, T = 1 << LOGT;
     const int qb = b - M, q = 1 << qb, half = 1 << (logR - 1);
@@ -249,8 +255,8 @@ __device__ __forceinline__ void dif_pass(int logR, int b, const float2* __restri
     }
 }
 // DIT pass with conjugated twiddles: the exact inverse data flow (unnormalised); no barrier inside
-template <int M, int LOGT, int TWM = 0, class Src, class Dst>
-__device__ __forceinline__ void dit_pass(int logR, int b, const float2* __restrict__ tw, int tid, int nthr, const Src& src,
+template <int M, int LOGT, int TWM = 0, class Src, class Dst, class TwT = const float2*>
+__device__ __forceinline__ void dit_pass(int logR, int b, const TwT& tw, int tid, int nthr, const Src& src,
                                          const Dst& dst) {
     constexpr int RAD = 1 << M, T = 1 << LOGT;
     const int qb = b - M, q = 1 << qb, half = 1 << (logR - 1);
@@ -648,8 +654,15 @@ struct FusedPlan {
     using IOA = std::conditional_t<BM == 8, LdsIOA<8>, LdsIO>;
     static constexpr int buf = LdsIO::pos(1 << LOGR) > IOA::pos(1 << LOGR) ? LdsIO::pos(1 << LOGR) : IOA::pos(1 << LOGR);
 };
-template <int LOGR>
-__device__ __forceinline__ void dif_first_from_regs(float2* x, const float2* __restrict__ tab, int tid, const float2 (&raw)[16]) {
+// Twiddle providers of the helpers below: a pointer to the passes' LDS tables (fused_tab_build), or FusedTw -- the
+// thread's own twiddles of the first / last pass (a) and of the middle pass (m) in registers (rows of 4096: one
+// butterfly per thread and pass, so the 2 x 15 values never change; 60 LDS reads per forward + inverse pair and the
+// 32 KiB of tables are gone for 60 VGPRs, which the default-plan build has to spare)
+struct FusedTw {
+    TwRegs a, m;
+};
+template <int LOGR, class TW>
+__device__ __forceinline__ void dif_first_from_regs(float2* x, const TW& tab, int tid, const float2 (&raw)[16]) {
     using P = FusedPlan<LOGR>;
     constexpr int M = P::M0, RAD = 1 << M, NIT = 16 / RAD, q = 1 << (LOGR - M), nthr = 1 << (LOGR - 4);
     const typename P::IOA io{x};
@@ -663,15 +676,23 @@ __device__ __forceinline__ void dif_first_from_regs(float2* x, const float2* __r
         dft_reg<RAD>(v);
         hd.st(0, v[0]);
 #pragma unroll
-        for (int k = 1; k < RAD; ++k) hd.st(brev_m<M>(k) * q, g_cmul(v[k], tab[(k - 1) * q + idx]));
+        for (int k = 1; k < RAD; ++k) {
+            float2 w;
+            if constexpr (std::is_same_v<TW, FusedTw>) w = tab.a.w[k - 1];
+            else w = tab[(k - 1) * q + idx];
+            hd.st(brev_m<M>(k) * q, g_cmul(v[k], w));
+        }
     }
 }
 // the middle pass and the 16-point blocks, whose butterfly ends in registers
-template <int LOGR>
-__device__ __forceinline__ void fft_dif_rest_to_regs(float2* x, const float2* __restrict__ tab, int tid, float2 (&out)[16]) {
+template <int LOGR, class TW>
+__device__ __forceinline__ void fft_dif_rest_to_regs(float2* x, const TW& tab, int tid, float2 (&out)[16]) {
     using P = FusedPlan<LOGR>;
     const LdsIO nb{x};
-    dif_pass<P::MM, 0, 2>(LOGR, P::BM, tab + fused_tab_off(LOGR, P::BM), tid, 1 << (LOGR - 4), typename P::IOA{x}, nb);
+    if constexpr (std::is_same_v<TW, FusedTw>)
+        dif_pass<P::MM, 0, 3>(LOGR, P::BM, tab.m, tid, 1 << (LOGR - 4), typename P::IOA{x}, nb);
+    else
+        dif_pass<P::MM, 0, 2>(LOGR, P::BM, tab + fused_tab_off(LOGR, P::BM), tid, 1 << (LOGR - 4), typename P::IOA{x}, nb);
     __syncthreads();
     const auto h = nb.open(tid << 4);
 #pragma unroll
@@ -680,8 +701,8 @@ __device__ __forceinline__ void fft_dif_rest_to_regs(float2* x, const float2* __
 }
 // v[k]: the (unswapped) input k of the thread's first DIT butterfly; result in LDS (natural order, layout A), no
 // barrier behind the last pass
-template <int LOGR>
-__device__ __forceinline__ void fft_dit_inv_from_regs(float2* x, const float2* __restrict__ tab, int tid, float2 (&v)[16]) {
+template <int LOGR, class TW>
+__device__ __forceinline__ void fft_dit_inv_from_regs(float2* x, const TW& tab, int tid, float2 (&v)[16]) {
     using P = FusedPlan<LOGR>;
     const LdsIO nb{x};
     const typename P::IOA io{x};
@@ -692,15 +713,29 @@ __device__ __forceinline__ void fft_dit_inv_from_regs(float2* x, const float2* _
 #pragma unroll
     for (int m = 0; m < 16; ++m) h.st(m, make_float2(v[m].y, v[m].x));
     __syncthreads();
-    dit_pass<P::MM, 0, 2>(LOGR, P::BM, tab + fused_tab_off(LOGR, P::BM), tid, 1 << (LOGR - 4), nb, io);
-    __syncthreads();
-    dit_pass<P::M0, 0, 2>(LOGR, LOGR, tab, tid, 1 << (LOGR - 4), io, io);
+    if constexpr (std::is_same_v<TW, FusedTw>) {
+        dit_pass<P::MM, 0, 3>(LOGR, P::BM, tab.m, tid, 1 << (LOGR - 4), nb, io);
+        __syncthreads();
+        dit_pass<P::M0, 0, 3>(LOGR, LOGR, tab.a, tid, 1 << (LOGR - 4), io, io);
+    } else {
+        dit_pass<P::MM, 0, 2>(LOGR, P::BM, tab + fused_tab_off(LOGR, P::BM), tid, 1 << (LOGR - 4), nb, io);
+        __syncthreads();
+        dit_pass<P::M0, 0, 2>(LOGR, LOGR, tab, tid, 1 << (LOGR - 4), io, io);
+    }
 }
 template <int NB>
 __device__ __forceinline__ void constexpr_pair(int ij, const float2 (&S)[NB][16], float2 (&v)[16]) {
     const int i = ij / NB, j = ij % NB;       // constant after unrolling
 #pragma unroll
     for (int k = 0; k < 16; ++k) v[k] = g_cmulc(S[j][k], S[i][k]);
+}
+// rows of 4096, default plan, at most 3 buoys: the passes' twiddles live in registers (FusedTw)
+__host__ __device__ constexpr bool fused_tw_regs(int nb, int logR, bool def) {
+#ifdef RMX_FUSED_NO_TWREG
+    return false;
+#else
+    return def && logR == 12 && nb <= 3;
+#endif
 }
 template <int NB, int LOGR, bool DEF = false>      // DEF: the default plan (all pairs i < j in order), pair loop unrolled
 __global__ __launch_bounds__(kGThreads, 2) void g_rows_fused(const float2* __restrict__ cols, float2* __restrict__ prod,
@@ -717,8 +752,21 @@ __global__ __launch_bounds__(kGThreads, 2) void g_rows_fused(const float2* __res
     float2* x = reinterpret_cast<float2*>(gsm) + g * P::buf;
     float2* t1 = reinterpret_cast<float2*>(gsm) + upw * P::buf + g * (n1 + n2);
     float2* t2 = t1 + n1;
-    float2* twl = reinterpret_cast<float2*>(gsm) + upw * (P::buf + n1 + n2);
-    fused_tab_build<LOGR, LOGR>(twl, tw);
+    constexpr bool TWREG = fused_tw_regs(NB, LOGR, DEF);
+    using TwSrc = std::conditional_t<TWREG, FusedTw, const float2*>;
+    TwSrc twl;
+    if constexpr (TWREG) {
+        static_assert(P::M0 == 4 && P::MM == 4 && tpr == kGThreads, "one radix-16 butterfly per thread and pass");
+#pragma unroll
+        for (int k = 1; k < 16; ++k) {
+            twl.a.w[k - 1] = tw_full(tw, tid * k, R >> 1);                                   // first / last pass: l = tid
+            twl.m.w[k - 1] = tw_full(tw, ((tid & 15) << (LOGR - P::BM)) * k, R >> 1);        // middle pass: l = tid & 15
+        }
+    } else {
+        float2* tl_ = reinterpret_cast<float2*>(gsm) + upw * (P::buf + n1 + n2);
+        fused_tab_build<LOGR, LOGR>(tl_, tw);
+        twl = tl_;
+    }
     const long n_blocks = (n_units + upw - 1) / upw;
     __syncthreads();
     // (persistent: 4.22 ms against 4.34 ms with one block per workgroup on cfg2 -- the tables are 32 KiB)

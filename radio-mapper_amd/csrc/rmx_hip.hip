@@ -1444,12 +1444,12 @@ static const void* fused_fn(int nb, int logR, bool def) {   // g_rows_fused<n_bu
     return nb == 2 ? RMX_FF(2, false) : nb == 3 ? RMX_FF(3, false) : RMX_FF(4, false);
 #undef RMX_FF
 }
-static size_t gen_fused_lds(int R) {                    // g_rows_fused: R/16 threads per row
+static size_t gen_fused_lds(int R, bool tw_regs = false) {   // g_rows_fused: R/16 threads per row (tw_regs: no twiddle tables)
     int logR = 0;
     while ((1 << logR) < R) ++logR;
     const int a = logR >> 1, tpr = R >> 4, upw = gen::kGThreads / (tpr > 0 ? tpr : 1);
     const int buf = logR == 9 ? gen::FusedPlan<9>::buf : logR == 10 ? gen::FusedPlan<10>::buf : logR == 11 ? gen::FusedPlan<11>::buf : gen::FusedPlan<12>::buf;
-    return ((size_t)upw * ((size_t)buf + (1 << a) + (R >> a)) + (size_t)gen::fused_tab_total(logR)) * 8;   // + the passes' twiddle tables
+    return ((size_t)upw * ((size_t)buf + (1 << a) + (R >> a)) + (size_t)(tw_regs ? 0 : gen::fused_tab_total(logR))) * 8;   // + the passes' twiddle tables
 }
 static int host_col_log_t(int l1) {                     // gen::col_log_t, or RMX_COL_LOGT (3 | 4) for experiments
     if (const char* e = getenv("RMX_COL_LOGT")) { const int v = atoi(e); if (v == 3 || v == 4) return v; }
@@ -1534,9 +1534,10 @@ static int generic_init(rmx_ctx* c) {
             c->g_fused_def_fn = fused_fn(c->n_buoys, c->g_logL2, true);
             if (const char* e = getenv("RMX_FUSED_DEF")) { if (atoi(e) == 0) c->g_fused_def_fn = nullptr; }
             if (c->g_fused_def_fn) {
-                RMX_HIP(c, hipFuncSetAttribute(c->g_fused_def_fn, hipFuncAttributeMaxDynamicSharedMemorySize, flds));
+                const int dlds = (int)gen_fused_lds(1 << c->g_logL2, gen::fused_tw_regs(c->n_buoys, c->g_logL2, true));
+                RMX_HIP(c, hipFuncSetAttribute(c->g_fused_def_fn, hipFuncAttributeMaxDynamicSharedMemorySize, dlds));
                 int pc = 0;
-                RMX_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, c->g_fused_def_fn, kGThreads, (size_t)flds));
+                RMX_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, c->g_fused_def_fn, kGThreads, (size_t)dlds));
                 c->g_fused_def_wgs = (pc > 0 ? pc : 1) * c->n_cus;
             }
             RMX_HIP(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, flds));
@@ -1695,7 +1696,8 @@ static int generic_pairs(rmx_ctx* c, int w0, int wc, int n_pairs, int* d_lag, fl
         long a_L = L, a_units = units;
         float a_scale = fs * fs;
         void* args[] = {&colsp, &prodp, &twp, &a_L1, &a_l1, &a_L, &a_lo, &thip, &tlop, &a_scale, &a_units, &pp, &a_np};
-        RMX_HIP(c, hipLaunchKernel(def_plan ? c->g_fused_def_fn : c->g_fused_fn, grid, dim3(kGThreads), args, gen_fused_lds(L2), st));
+        RMX_HIP(c, hipLaunchKernel(def_plan ? c->g_fused_def_fn : c->g_fused_fn, grid, dim3(kGThreads), args,
+                                   gen_fused_lds(L2, def_plan && gen::fused_tw_regs(B, l2, true)), st));
     } else
     {
         float2* a_data = c->g_prod;
