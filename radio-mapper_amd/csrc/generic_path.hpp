@@ -767,10 +767,11 @@ __global__ __launch_bounds__(kGThreads, 2) void g_rows_fused(const float2* __res
         fused_tab_build<LOGR, LOGR>(tl_, tw);
         twl = tl_;
     }
-    const long n_blocks = (n_units + upw - 1) / upw;
     __syncthreads();
-    // (persistent: 4.22 ms against 4.34 ms with one block per workgroup on cfg2 -- the tables are 32 KiB)
-    for (long blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+    // One block of upw units per workgroup.  (While the kernel still had a run-time pair loop a persistent workgroup --
+    // tables built once -- was 3 % faster; with the pair loop unrolled and the 4096-point twiddles in registers the
+    // straight-line kernel is as fast or up to 4 % faster.)
+    {   const long blk = blockIdx.x;
         // the block's units are rows rib0 .. rib0 + upw - 1 of one window (upw divides n_rows); addresses below are a
         // workgroup-uniform base (SGPRs) plus a 32-bit offset per thread
         const long unit0 = blk * upw;

@@ -1175,10 +1175,8 @@ struct rmx_ctx {
     int g_logL = 0, g_logL1 = 0, g_logL2 = 0, g_lo_bits = 0, g_chunk = 0;
     bool g_fused = false;      // four-step: both row passes in g_rows_fused (n_buoys <= 4, plain batches)
     bool g_fused_always = false;
-    int g_fused_wgs = 0;       // its persistent grid
     const void* g_fused_fn = nullptr;
     const void* g_fused_def_fn = nullptr;  // the same for the default plan (pair loop unrolled)
-    int g_fused_def_wgs = 0;
     const void* g_cols_inv_fn = nullptr;
     const void* g_cols_fwd_fn[2] = {nullptr, nullptr};   // [u8]
     const void* g_rows_inv_fn = nullptr;
@@ -1536,14 +1534,8 @@ static int generic_init(rmx_ctx* c) {
             if (c->g_fused_def_fn) {
                 const int dlds = (int)gen_fused_lds(1 << c->g_logL2, gen::fused_tw_regs(c->n_buoys, c->g_logL2, true));
                 RMX_HIP(c, hipFuncSetAttribute(c->g_fused_def_fn, hipFuncAttributeMaxDynamicSharedMemorySize, dlds));
-                int pc = 0;
-                RMX_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, c->g_fused_def_fn, kGThreads, (size_t)dlds));
-                c->g_fused_def_wgs = (pc > 0 ? pc : 1) * c->n_cus;
             }
             RMX_HIP(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, flds));
-            int per_cu = 0;
-            RMX_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kGThreads, (size_t)flds));
-            c->g_fused_wgs = (per_cu > 0 ? per_cu : 1) * c->n_cus;
         }
     }
     // windows per chunk: spectra (B*L) + products (P*L), 8 bytes each, under 32 GiB of the 288 (cfg2's 64
@@ -1685,8 +1677,7 @@ static int generic_pairs(rmx_ctx* c, int w0, int wc, int n_pairs, int* d_lag, fl
         const int upw = kGThreads / (L2 >> 4 > 0 ? L2 >> 4 : 1);
         const long blocks = (units + upw - 1) / upw;
         const bool def_plan = c->g_fused_def_fn && c->plan_all_pairs && n_pairs == B * (B - 1) / 2;
-        const long wgs = def_plan ? c->g_fused_def_wgs : c->g_fused_wgs;
-        const dim3 grid((unsigned)(blocks < wgs ? blocks : wgs));
+        const dim3 grid((unsigned)blocks);
         const float fs = std::ldexp(1.0f, -(logL / 2));
         const float2* colsp = c->g_spec;
         float2* prodp = c->g_prod;
