@@ -701,8 +701,9 @@ __device__ __forceinline__ void fft_dif_rest_to_regs(float2* x, const TW& tab, i
 }
 // v[k]: the (unswapped) input k of the thread's first DIT butterfly; result in LDS (natural order, layout A), no
 // barrier behind the last pass
-template <int LOGR, class TW>
-__device__ __forceinline__ void fft_dit_inv_from_regs(float2* x, const TW& tab, int tid, float2 (&v)[16]) {
+// `last`: where the last pass writes (default: the buffer, layout A)
+template <int LOGR, class TW, class Last>
+__device__ __forceinline__ void fft_dit_inv_from_regs(float2* x, const TW& tab, int tid, float2 (&v)[16], const Last& last) {
     using P = FusedPlan<LOGR>;
     const LdsIO nb{x};
     const typename P::IOA io{x};
@@ -716,12 +717,16 @@ __device__ __forceinline__ void fft_dit_inv_from_regs(float2* x, const TW& tab, 
     if constexpr (std::is_same_v<TW, FusedTw>) {
         dit_pass<P::MM, 0, 3>(LOGR, P::BM, tab.m, tid, 1 << (LOGR - 4), nb, io);
         __syncthreads();
-        dit_pass<P::M0, 0, 3>(LOGR, LOGR, tab.a, tid, 1 << (LOGR - 4), io, io);
+        dit_pass<P::M0, 0, 3>(LOGR, LOGR, tab.a, tid, 1 << (LOGR - 4), io, last);
     } else {
         dit_pass<P::MM, 0, 2>(LOGR, P::BM, tab + fused_tab_off(LOGR, P::BM), tid, 1 << (LOGR - 4), nb, io);
         __syncthreads();
-        dit_pass<P::M0, 0, 2>(LOGR, LOGR, tab, tid, 1 << (LOGR - 4), io, io);
+        dit_pass<P::M0, 0, 2>(LOGR, LOGR, tab, tid, 1 << (LOGR - 4), io, last);
     }
+}
+template <int LOGR, class TW>
+__device__ __forceinline__ void fft_dit_inv_from_regs(float2* x, const TW& tab, int tid, float2 (&v)[16]) {
+    fft_dit_inv_from_regs<LOGR>(x, tab, tid, v, typename FusedPlan<LOGR>::IOA{x});
 }
 template <int NB>
 __device__ __forceinline__ void constexpr_pair(int ij, const float2 (&S)[NB][16], float2 (&v)[16]) {
@@ -852,6 +857,172 @@ __global__ __launch_bounds__(kGThreads, 2) void g_rows_fused(const float2* __res
                     }
                 finish(v, q);
             }
+        }
+    }
+}
+
+// ---- whole windows in one kernel (few buoys, 512 <= L <= 4096) -------------------------------------------------
+// The two-kernel LDS path (g_fwd_small, g_pair_small) writes every spectrum to HBM and reads two of them back per
+// pair: (24 B + 32 P) N bytes per window against 8 B N of input -- at 4096 windows of 2048 samples the spectra
+// (400 MB for 3 buoys) do not even stay in the memory-side cache.  With at most four buoys a window's spectra fit the
+// registers of the R / 16 threads that transform it (g_rows_fused's blocks, the "row" being the whole zero-padded
+// window): the kernel reads the samples once (the zero half never: literal zeros in the first butterfly), forms every
+// pair's product in registers, runs the inverse in LDS and folds the peak scan into the inverse's last pass, which
+// leaves only |r|^2 behind for the two neighbour taps.  HBM traffic: the input and 12 bytes per pair.
+// 256 / (R / 16) windows per workgroup.  sv / sk: two words per wave for the cross-wave step of the argmax.
+template <int TPR>
+__device__ __forceinline__ void group_argmax(float& v, int& k, float* sv, int* sk, int gtid, int g) {
+    constexpr int W = TPR < 64 ? TPR : 64;
+#pragma unroll
+    for (int off = W >> 1; off >= 1; off >>= 1) {
+        const float ov = __shfl_xor(v, off, 64);
+        const int ok = __shfl_xor(k, off, 64);
+        if (ov > v || (ov == v && ok < k)) { v = ov; k = ok; }
+    }
+    if constexpr (TPR > 64) {
+        constexpr int NW = TPR / 64;
+        if ((gtid & 63) == 0) { sv[g * NW + (gtid >> 6)] = v; sk[g * NW + (gtid >> 6)] = k; }
+        __syncthreads();
+        v = sv[g * NW];
+        k = sk[g * NW];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) {
+            const float ov = sv[g * NW + w];
+            const int ok = sk[g * NW + w];
+            if (ov > v || (ov == v && ok < k)) { v = ov; k = ok; }
+        }
+    }
+}
+__host__ __device__ constexpr int default_pair_code(int nb, int q) {     // i * nb + j of the q-th pair i < j, i-major
+    int i = 0;
+    while (q >= nb - 1 - i) { q -= nb - 1 - i; ++i; }
+    return i * nb + (i + 1 + q);
+}
+template <class F, int... Q>
+__device__ __forceinline__ void for_each_q(F&& f, std::integer_sequence<int, Q...>) { (f(std::integral_constant<int, Q>{}), ...); }
+template <int NB, class F>
+__device__ __forceinline__ void for_each_default_pair(F&& f) { for_each_q(f, std::make_integer_sequence<int, NB * (NB - 1) / 2>{}); }
+template <int NB, int LOGR, bool DEF, bool U8>
+__global__ __launch_bounds__(kGThreads, 2) void g_win_fused(const void* __restrict__ iq, const float2* __restrict__ tw,
+                                                         long n_windows, long first_window, float fwd_scale,
+                                                         float out_scale, const GPair* __restrict__ pairs, int n_pairs,
+                                                         int* __restrict__ lag_int, float* __restrict__ lag_frac,
+                                                         float* __restrict__ peak) {
+    extern __shared__ __attribute__((aligned(16))) char gsm[];
+    constexpr int R = 1 << LOGR, N = R >> 1, tpr = R >> 4, upw = kGThreads / tpr;   // threads per window, windows per workgroup
+    using P = FusedPlan<LOGR>;
+    constexpr int M0 = P::M0;
+    const int g = threadIdx.x / tpr, tid = threadIdx.x % tpr;
+    float2* x = reinterpret_cast<float2*>(gsm) + g * P::buf;
+    constexpr bool TWREG = fused_tw_regs(NB, LOGR, DEF);
+    using TwSrc = std::conditional_t<TWREG, FusedTw, const float2*>;
+    TwSrc twl;
+    float* sv;
+    if constexpr (TWREG) {
+#pragma unroll
+        for (int k = 1; k < 16; ++k) {
+            twl.a.w[k - 1] = tw_full(tw, tid * k, R >> 1);
+            twl.m.w[k - 1] = tw_full(tw, ((tid & 15) << (LOGR - P::BM)) * k, R >> 1);
+        }
+        sv = reinterpret_cast<float*>(reinterpret_cast<float2*>(gsm) + upw * P::buf);
+    } else {
+        float2* tl_ = reinterpret_cast<float2*>(gsm) + upw * P::buf;
+        fused_tab_build<LOGR, LOGR>(tl_, tw);
+        twl = tl_;
+        sv = reinterpret_cast<float*>(tl_ + fused_tab_total(LOGR));
+    }
+    int* sk = reinterpret_cast<int*>(sv + 8);
+    __syncthreads();
+    const long w = (long)blockIdx.x * upw + g;
+    const bool live = w < n_windows;
+    float2 S[NB][16];
+    {   // every buoy's first-pass inputs, all loads in flight together; the zero-padded half is never read
+        constexpr int RAD = 1 << M0, qq = R >> M0;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const long base = (w * NB + b) * (long)N;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                if ((e % RAD) < RAD / 2 && live) {
+                    const long n = base + (tid + (e / RAD) * tpr + (e % RAD) * qq);
+                    if constexpr (U8) {
+                        const uchar2 b8 = reinterpret_cast<const uchar2*>(iq)[n];
+                        S[b][e] = make_float2((float)b8.x - 127.5f, (float)b8.y - 127.5f);
+                    } else {
+                        S[b][e] = reinterpret_cast<const float2*>(iq)[n];
+                    }
+                } else {
+                    S[b][e] = make_float2(0.f, 0.f);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        int tl = tid;                         // (opaque copy: keeps the passes' address arithmetic inside the loop)
+        asm volatile("" : "+v"(tl));
+        dif_first_from_regs<LOGR>(x, twl, tl, S[b]);
+        __syncthreads();
+        fft_dif_rest_to_regs<LOGR>(x, twl, tl, S[b]);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) S[b][k] = make_float2(S[b][k].x * fwd_scale, S[b][k].y * fwd_scale);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();                      // the next transform's first pass overwrites x
+    }
+    const long obase = (first_window + w) * (long)n_pairs;
+    // inverse of the product in v; the last pass keeps (max |r|^2, lowest 'full' index) per thread and leaves |r|^2
+    auto finish = [&](float2 (&v)[16], int q) __attribute__((always_inline)) {
+        int tl = tid;
+        asm volatile("" : "+v"(tl));
+        float best = -1.0f;
+        int bk = 0x7fffffff;
+        fft_dit_inv_from_regs<LOGR>(x, twl, tl, v, make_dst([&](int E0, int off, float2 e) __attribute__((always_inline)) {
+            const int n = E0 + off;
+            const float m2 = e.x * e.x + e.y * e.y;
+            if (m2 >= best) {
+                const int k = full_index(n, N);
+                if (k >= 0 && (m2 > best || k < bk)) { best = m2; bk = k; }
+            }
+            x[P::IOA::pos(n)].x = m2;
+        }));
+        __syncthreads();
+        group_argmax<tpr>(best, bk, sv, sk, tl, g);
+        if (tl == 0 && live) {
+            const float b = sqrtf(best) * out_scale;
+            float frac = 0.0f;
+            if (bk > 0 && bk < 2 * N - 2) {
+                const float ra = x[P::IOA::pos(circ_index(bk - 1, N))].x, rc = x[P::IOA::pos(circ_index(bk + 1, N))].x;
+                frac = parabola(sqrtf(ra) * out_scale, b, sqrtf(rc) * out_scale);
+            }
+            lag_int[obase + q] = bk - (N - 1);
+            lag_frac[obase + q] = frac;
+            peak[obase + q] = b;
+        }
+        __syncthreads();                      // x, sv are rewritten by the next pair
+    };
+    if constexpr (DEF) {
+        // the default plan, pair q = (i, j) with i < j, i-major: unrolled by pack expansion (a "#pragma unroll" loop nest
+        // of this size is left rolled by hipcc at 4 buoys x 4096 points, and the spectra then live in scratch memory)
+        for_each_default_pair<NB>([&](auto qc) __attribute__((always_inline)) {
+            constexpr int q = decltype(qc)::value;
+            float2 v[16];
+            constexpr int code = default_pair_code(NB, q);
+            constexpr_pair<NB>(code, S, v);
+            finish(v, q);
+        });
+    } else {
+        for (int q = 0; q < n_pairs; ++q) {
+            const GPair pr = pairs[q];
+            float2 v[16];
+            const int code = pr.i * NB + pr.j;
+            constexpr_pair<NB>(0, S, v);
+#pragma unroll
+            for (int ij = 1; ij < NB * NB; ++ij)
+                if (code == ij) {
+                    asm volatile("" ::: "memory");
+                    constexpr_pair<NB>(ij, S, v);
+                }
+            finish(v, q);
         }
     }
 }

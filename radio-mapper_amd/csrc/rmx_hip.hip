@@ -1177,6 +1177,9 @@ struct rmx_ctx {
     bool g_fused_always = false;
     const void* g_fused_fn = nullptr;
     const void* g_fused_def_fn = nullptr;  // the same for the default plan (pair loop unrolled)
+    bool g_wfused = false;     // LDS-resident lengths, n_buoys <= 4: whole windows in g_win_fused (no spectra in HBM)
+    const void* g_wf_fn[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [default plan][u8]
+    size_t g_wf_lds[2] = {0, 0};           // [default plan]
     const void* g_cols_inv_fn = nullptr;
     const void* g_cols_fwd_fn[2] = {nullptr, nullptr};   // [u8]
     const void* g_rows_inv_fn = nullptr;
@@ -1442,6 +1445,18 @@ static const void* fused_fn(int nb, int logR, bool def) {   // g_rows_fused<n_bu
     return nb == 2 ? RMX_FF(2, false) : nb == 3 ? RMX_FF(3, false) : RMX_FF(4, false);
 #undef RMX_FF
 }
+template <bool DEF, bool U8>
+static const void* wfused_fn(int nb, int logR) {            // g_win_fused<n_buoys, log2 L, default plan, uint8 input>
+#define RMX_WF(NB) (logR == 9 ? (const void*)gen::g_win_fused<NB, 9, DEF, U8> : logR == 10 ? (const void*)gen::g_win_fused<NB, 10, DEF, U8> : \
+                    logR == 11 ? (const void*)gen::g_win_fused<NB, 11, DEF, U8> : (const void*)gen::g_win_fused<NB, 12, DEF, U8>)
+    return nb == 2 ? RMX_WF(2) : nb == 3 ? RMX_WF(3) : RMX_WF(4);
+#undef RMX_WF
+}
+static size_t gen_wfused_lds(int logR, bool tw_regs) {     // transform buffers + the passes' twiddle tables + argmax words
+    const int tpr = (1 << logR) >> 4, upw = gen::kGThreads / tpr;
+    const int buf = logR == 9 ? gen::FusedPlan<9>::buf : logR == 10 ? gen::FusedPlan<10>::buf : logR == 11 ? gen::FusedPlan<11>::buf : gen::FusedPlan<12>::buf;
+    return ((size_t)upw * buf + (size_t)(tw_regs ? 0 : gen::fused_tab_total(logR)) + 8) * 8;
+}
 static size_t gen_fused_lds(int R, bool tw_regs = false) {   // g_rows_fused: R/16 threads per row (tw_regs: no twiddle tables)
     int logR = 0;
     while ((1 << logR) < R) ++logR;
@@ -1480,6 +1495,21 @@ static int generic_init(rmx_ctx* c) {
         RMX_HIP(c, hipFuncSetAttribute((const void*)g_pair_small, hipFuncAttributeMaxDynamicSharedMemorySize, slds));
         RMX_HIP(c, hipFuncSetAttribute((const void*)g_fwd_small<false>, hipFuncAttributeMaxDynamicSharedMemorySize, slds));
         RMX_HIP(c, hipFuncSetAttribute((const void*)g_fwd_small<true>, hipFuncAttributeMaxDynamicSharedMemorySize, slds));
+        // at most four buoys, 512 <= L <= 4096: whole windows in one kernel, spectra in registers (RMX_WFUSED=0: the two
+        // kernels above, as for custom Doppler searches)
+        c->g_wfused = c->n_buoys >= 2 && c->n_buoys <= 4 && c->g_logL >= 9 && c->g_logL <= 12;
+        if (const char* e = getenv("RMX_WFUSED")) c->g_wfused = c->g_wfused && atoi(e) != 0;
+        if (c->g_wfused) {
+            c->g_wf_fn[0][0] = wfused_fn<false, false>(c->n_buoys, c->g_logL);
+            c->g_wf_fn[0][1] = wfused_fn<false, true>(c->n_buoys, c->g_logL);
+            c->g_wf_fn[1][0] = wfused_fn<true, false>(c->n_buoys, c->g_logL);
+            c->g_wf_fn[1][1] = wfused_fn<true, true>(c->n_buoys, c->g_logL);
+            c->g_wf_lds[0] = gen_wfused_lds(c->g_logL, false);
+            c->g_wf_lds[1] = gen_wfused_lds(c->g_logL, gen::fused_tw_regs(c->n_buoys, c->g_logL, true));
+            for (int d = 0; d < 2; ++d)
+                for (int u = 0; u < 2; ++u)
+                    RMX_HIP(c, hipFuncSetAttribute(c->g_wf_fn[d][u], hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->g_wf_lds[d]));
+        }
     } else {
         // columns of length L1 <= 1024 (a tile of 16 columns is L1*128 bytes of LDS), rows of L2 = L/L1 <= 8192
         // columns a little shorter than rows (measured: 512 x 4096 beats 1024 x 2048 at L = 2^21, 256 x 2048 beats
@@ -1549,11 +1579,11 @@ static int generic_init(rmx_ctx* c) {
     return RMX_OK;
 }
 
-static int generic_ensure(rmx_ctx* c, int n_pairs) {
+static int generic_ensure(rmx_ctx* c, int n_pairs, bool need_spec = true) {
     using namespace gen;
     const long L = 1L << c->g_logL;
     const long items = (long)c->g_chunk * c->n_buoys, slots = (long)c->g_chunk * n_pairs;
-    if (!c->g_spec) {
+    if (!c->g_spec && need_spec) {
         RMX_HIP(c, hipMalloc((void**)&c->g_spec, items * L * 8));
         c->scratch_bytes += items * L * 8;
     }
@@ -1717,8 +1747,24 @@ static int generic_pairs(rmx_ctx* c, int w0, int wc, int n_pairs, int* d_lag, fl
 
 static int generic_batch(rmx_ctx* c, const void* d_iq, int n_windows, int n_pairs, int* d_lag, float* d_frac,
                          float* d_peak, bool u8) {
-    int rc = generic_ensure(c, n_pairs);
+    int rc = generic_ensure(c, n_pairs, !c->g_wfused);
     if (rc) return rc;
+    if (c->g_wfused) {
+        using namespace gen;
+        const int logL = c->g_logL, B = c->n_buoys, hs = logL / 2;
+        const bool def_plan = c->plan_all_pairs && n_pairs == B * (B - 1) / 2;
+        const int upw = kGThreads / ((1 << logL) >> 4);
+        const void* a_iq = d_iq;
+        const float2* a_tw = c->g_tw;
+        long a_nw = n_windows, a_first = 0;
+        float a_fs = std::ldexp(1.0f, -hs), a_os = std::ldexp(1.0f, -(logL - 2 * hs));
+        const GPair* a_pairs = c->g_pairs;
+        int a_np = n_pairs;
+        void* args[] = {&a_iq, &a_tw, &a_nw, &a_first, &a_fs, &a_os, &a_pairs, &a_np, &d_lag, &d_frac, &d_peak};
+        RMX_HIP(c, hipLaunchKernel(c->g_wf_fn[def_plan ? 1 : 0][u8 ? 1 : 0], dim3((unsigned)((n_windows + upw - 1) / upw)),
+                                   dim3(kGThreads), args, c->g_wf_lds[def_plan ? 1 : 0], c->stream));
+        return RMX_OK;
+    }
     for (int w0 = 0; w0 < n_windows; w0 += c->g_chunk) {
         const int wc = n_windows - w0 < c->g_chunk ? n_windows - w0 : c->g_chunk;
         // the fused row kernel when its (window, row block) units fill the chip at least twice: below that (cfg1's single

@@ -624,6 +624,31 @@ def test_fused_row_kernel_by_row_length(xc, N, B, monkeypatch):
     assert np.array_equal(ui, li) and np.all(np.abs(uf - lf) <= TOL) and np.allclose(up, pk, rtol=1e-5)
 
 
+@pytest.mark.parametrize("N,B", [(256, 2), (256, 4), (512, 3), (1024, 4), (1024, 2), (2048, 3), (2048, 4)])
+def test_whole_window_kernel_by_length(xc, N, B, monkeypatch):
+    """LDS-resident lengths with up to 4 buoys run whole windows in one kernel (g_win_fused, compiled for L = 2^9 ..
+    2^12; the spectra exist in registers only): every length and buoy count against the oracle on complex64 and raw
+    uint8 input, a window count that leaves the last workgroup partly empty, a custom pair list with a reversed, a
+    repeated and an autocorrelation pair, and the two-kernel path (RMX_WFUSED=0) on the same input."""
+    W = 19
+    iq, _, raw = rm.synth.make_windows(W, B, N, 2.4e6, seed=700 + B + N % 977, return_u8=True)
+    ri, rf, rp = orc.xcorr_batch_literal(iq)
+    margin = np.array([[orc.peak_margin(iq[w, i], iq[w, j]) for (i, j) in orc.pair_list(B)] for w in range(W)])
+    custom = np.array([(B - 1, 0), (0, 1), (1, 1), (0, 1)], np.int32)
+    with xc.XcorrEngine(B, N, W) as eng:
+        li, lf, pk = eng.correlate(iq)
+        l8, f8, p8 = eng.correlate(raw)
+        ci, cf, cp = eng.correlate(iq, custom)
+    _assert_parity(li, lf, pk, ri, rf, rp, margin)
+    assert np.array_equal(li, l8) and np.array_equal(lf, f8) and np.array_equal(pk, p8)
+    oi, of_, op = orc.xcorr_batch_literal(iq, custom)
+    _assert_parity(ci, cf, cp, oi, of_, op)
+    monkeypatch.setenv("RMX_WFUSED", "0")
+    with xc.XcorrEngine(B, N, W) as eng:
+        ui, uf, up = eng.correlate(iq)
+    assert np.array_equal(ui, li) and np.all(np.abs(uf - lf) <= TOL) and np.allclose(up, pk, rtol=1e-5)
+
+
 @pytest.mark.parametrize("case", range(12))
 def test_seeded_random_shapes_and_pair_lists(xc, case):
     """Seeded sweep over (buoys, window length, windows, pair list): every kernel family gets shapes nobody
