@@ -1027,6 +1027,194 @@ __global__ __launch_bounds__(kGThreads, 2) void g_win_fused(const void* __restri
     }
 }
 
+// ---- whole windows in one kernel, any number of buoys, 512 <= L <= 16384 (N = 8192: the reference's capture length) --
+// The same idea with the spectra in a per-workgroup scratch instead of registers: a persistent workgroup (R / 16
+// threads per window, one radix-16 butterfly per thread and pass) transforms the window's buoys one after the other
+// and parks each spectrum -- in the register order of its last butterfly, 16 bytes per lane, coalesced -- in its own
+// n_buoys x 8 R bytes of global memory, which it overwrites window after window: the scratch of the whole grid stays
+// in the L2 / memory-side cache, HBM sees the input.  Every pair then loads its two spectra back (each thread exactly
+// the values it stored: no visibility protocol), multiplies in registers, and runs the inverse with the peak scan in
+// its last pass.  L = 16384 is one 136 KiB transform per CU with 1024 threads; its first pass's twiddles live in
+// registers (one butterfly per thread: they never change), the others' in small LDS tables.
+// Pass order: radix 16 from the whole window down (DIF) while more than four stages remain, the left-over 1..4
+// stages last, on the thread's 16 neighbouring elements: they end in registers, and the inverse starts there.
+template <int LOGR>
+struct WinPlan {
+    static constexpr int R = 1 << LOGR, tpr = R >> 4;
+    static constexpr int ML = ((LOGR - 1) & 3) + 1, RADL = 1 << ML, NITL = 16 / RADL;   // the neighbour pass
+    static constexpr int NP = (LOGR - ML) / 4;                                            // radix-16 passes, blocks LOGR, LOGR - 4, ..
+    static constexpr bool TW1REG = LOGR >= 12;                                            // first pass's twiddles in registers
+    static constexpr int thr = tpr < kGThreads ? kGThreads : tpr, upw = thr / tpr;         // threads, windows per workgroup
+    static constexpr int tab_off(int b) {                                                 // entries in front of pass b's LDS table
+        int acc = 0;
+        for (int c = LOGR; c > b; c -= 4)
+            if (!(c == LOGR && TW1REG)) acc += 15 << (c - 4);
+        return acc;
+    }
+    static constexpr int tab_total = tab_off(ML);
+    static constexpr size_t lds_bytes = ((size_t)upw * lp(R) + tab_total + 16) * 8;
+};
+template <int LOGR, bool U8>
+__global__ __launch_bounds__(WinPlan<LOGR>::thr) void g_win_scr(const void* __restrict__ iq, float4* __restrict__ scratch,
+                                                             const float2* __restrict__ tw, int n_buoys, long n_windows,
+                                                             long first_window, float fwd_scale, float out_scale,
+                                                             const GPair* __restrict__ pairs, int n_pairs,
+                                                             int* __restrict__ lag_int, float* __restrict__ lag_frac,
+                                                             float* __restrict__ peak) {
+    extern __shared__ __attribute__((aligned(16))) char gsm[];
+    using P = WinPlan<LOGR>;
+    constexpr int R = P::R, N = R >> 1, tpr = P::tpr, upw = P::upw, ML = P::ML, RADL = P::RADL, NITL = P::NITL;
+    const int g = threadIdx.x / tpr, tid = threadIdx.x % tpr;
+    float2* x = reinterpret_cast<float2*>(gsm) + g * lp(R);
+    float2* tab = reinterpret_cast<float2*>(gsm) + upw * lp(R);
+    float* sv = reinterpret_cast<float*>(tab + P::tab_total);
+    int* sk = reinterpret_cast<int*>(sv + 16);
+    {   // the passes' tables [k = 1..15][l < q]: W_R^(l k 2^(LOGR - b)), consecutive lanes read consecutive entries
+        auto build = [&](auto bc) __attribute__((always_inline)) {
+            constexpr int b = decltype(bc)::value, q = 1 << (b - 4), off = P::tab_off(b);
+            for (int e = threadIdx.x; e < 15 * q; e += P::thr)
+                tab[off + e] = tw_full(tw, ((e & (q - 1)) << (LOGR - b)) * ((e >> (b - 4)) + 1), R >> 1);
+        };
+        if constexpr (!P::TW1REG) build(std::integral_constant<int, LOGR>{});
+        if constexpr (P::NP >= 2) build(std::integral_constant<int, LOGR - 4>{});
+        if constexpr (P::NP >= 3) build(std::integral_constant<int, LOGR - 8>{});
+    }
+    TwRegs tw1;
+    if constexpr (P::TW1REG) {
+#pragma unroll
+        for (int k = 1; k < 16; ++k) tw1.w[k - 1] = tw_full(tw, tid * k, R >> 1);
+    }
+    __syncthreads();
+    const LdsIO lds{x};
+    float4* scr = scratch + ((long)blockIdx.x * upw + g) * n_buoys * (8L * tpr) + tid;
+    for (long blk = blockIdx.x; blk * upw < n_windows; blk += gridDim.x) {
+        const long w = blk * upw + g;
+        const bool live = w < n_windows;
+        auto load_in = [&](float2 (&d)[8], int b) __attribute__((always_inline)) {
+            const long base = (w * n_buoys + b) * (long)N + tid;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                if (!live) { d[m] = make_float2(0.f, 0.f); continue; }
+                if constexpr (U8) {
+                    const uchar2 b8 = reinterpret_cast<const uchar2*>(iq)[base + m * tpr];
+                    d[m] = make_float2((float)b8.x - 127.5f, (float)b8.y - 127.5f);
+                } else {
+                    d[m] = reinterpret_cast<const float2*>(iq)[base + m * tpr];
+                }
+            }
+        };
+        float2 nx[8];
+        load_in(nx, 0);
+        for (int b = 0; b < n_buoys; ++b) {
+            float2 v[16];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) { v[m] = nx[m]; v[m + 8] = make_float2(0.f, 0.f); }   // the zero-padded half: literal zeros
+            if (b + 1 < n_buoys) load_in(nx, b + 1);                                           // travels during this transform
+            {   // first pass: the whole window, elements tid + m R/16
+                dft16(v);
+                const auto hd = lds.open(tid);
+                hd.st(0, v[0]);
+#pragma unroll
+                for (int k = 1; k < 16; ++k) {
+                    float2 wk;
+                    if constexpr (P::TW1REG) wk = tw1.w[k - 1];
+                    else wk = tab[(k - 1) * tpr + tid];
+                    hd.st(brev_m<4>(k) * tpr, g_cmul(v[k], wk));
+                }
+            }
+            __syncthreads();
+            if constexpr (P::NP >= 2) {
+                constexpr int bb = LOGR - 4, off = P::tab_off(bb);
+                dif_pass<4, 0, 2>(LOGR, bb, tab + off, tid, tpr, lds, lds);
+                __syncthreads();
+            }
+            if constexpr (P::NP >= 3) {
+                constexpr int bb = LOGR - 8, off = P::tab_off(bb);
+                dif_pass<4, 0, 2>(LOGR, bb, tab + off, tid, tpr, lds, lds);
+                __syncthreads();
+            }
+            {   // the thread's 16 neighbours: 16 / 2^ML butterflies, outputs stay in registers (butterfly order)
+                const auto h = lds.open(tid << 4);
+#pragma unroll
+                for (int it = 0; it < NITL; ++it) {
+                    float2 t[RADL];
+#pragma unroll
+                    for (int m = 0; m < RADL; ++m) t[m] = h.ld(it * RADL + m);
+                    dft_reg<RADL>(t);
+#pragma unroll
+                    for (int m = 0; m < RADL; ++m) v[it * RADL + m] = t[m];
+                }
+            }
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk)
+                scr[(long)(b * 8 + kk) * tpr] = make_float4(v[2 * kk].x * fwd_scale, v[2 * kk].y * fwd_scale,
+                                                             v[2 * kk + 1].x * fwd_scale, v[2 * kk + 1].y * fwd_scale);
+            __syncthreads();                      // the next transform's first pass overwrites x
+        }
+        const long obase = (first_window + w) * (long)n_pairs;
+        for (int q = 0; q < n_pairs; ++q) {
+            const GPair pr = pairs[q];
+            float2 v[16];
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {      // X_j conj(X_i), element by element of the thread's own 16
+                const float4 a = scr[(long)(pr.j * 8 + kk) * tpr], c = scr[(long)(pr.i * 8 + kk) * tpr];
+                v[2 * kk] = g_cmulc(make_float2(a.x, a.y), make_float2(c.x, c.y));
+                v[2 * kk + 1] = g_cmulc(make_float2(a.z, a.w), make_float2(c.z, c.w));
+            }
+            {   // inverse, first pass: the same neighbour butterflies ((im, re)-swapped data: swap o DFT o swap = conj DFT)
+                const auto h = lds.open(tid << 4);
+#pragma unroll
+                for (int it = 0; it < NITL; ++it) {
+                    float2 t[RADL];
+#pragma unroll
+                    for (int k = 0; k < RADL; ++k) t[k] = make_float2(v[it * RADL + k].y, v[it * RADL + k].x);
+                    dft_reg<RADL>(t);
+#pragma unroll
+                    for (int m = 0; m < RADL; ++m) h.st(it * RADL + m, make_float2(t[m].y, t[m].x));
+                }
+            }
+            __syncthreads();
+            if constexpr (P::NP >= 3) {
+                constexpr int bb = LOGR - 8, off = P::tab_off(bb);
+                dit_pass<4, 0, 2>(LOGR, bb, tab + off, tid, tpr, lds, lds);
+                __syncthreads();
+            }
+            if constexpr (P::NP >= 2) {
+                constexpr int bb = LOGR - 4, off = P::tab_off(bb);
+                dit_pass<4, 0, 2>(LOGR, bb, tab + off, tid, tpr, lds, lds);
+                __syncthreads();
+            }
+            float best = -1.0f;
+            int bk = 0x7fffffff;
+            const auto scan = make_dst([&](int E0, int off, float2 e) __attribute__((always_inline)) {
+                const int n = E0 + off;
+                const float m2 = e.x * e.x + e.y * e.y;
+                if (m2 >= best) {
+                    const int k = full_index(n, N);
+                    if (k >= 0 && (m2 > best || k < bk)) { best = m2; bk = k; }
+                }
+                x[lp(n)].x = m2;
+            });
+            if constexpr (P::TW1REG) dit_pass<4, 0, 3>(LOGR, LOGR, tw1, tid, tpr, lds, scan);
+            else dit_pass<4, 0, 2>(LOGR, LOGR, tab, tid, tpr, lds, scan);
+            __syncthreads();
+            group_argmax<tpr>(best, bk, sv, sk, tid, g);
+            if (tid == 0 && live) {
+                const float bpk = sqrtf(best) * out_scale;
+                float frac = 0.0f;
+                if (bk > 0 && bk < 2 * N - 2) {
+                    const float ra = x[lp(circ_index(bk - 1, N))].x, rc = x[lp(circ_index(bk + 1, N))].x;
+                    frac = parabola(sqrtf(ra) * out_scale, bpk, sqrtf(rc) * out_scale);
+                }
+                lag_int[obase + q] = bk - (N - 1);
+                lag_frac[obase + q] = frac;
+                peak[obase + q] = bpk;
+            }
+            __syncthreads();                      // x, sv are rewritten
+        }
+    }
+}
+
 // ---- column passes of the four-step (no transposes through HBM) ----------------------------------
 // The L-point sequence is the row-major matrix [L1][L2], n = n1*L2 + n2.  A workgroup takes a tile of
 // T = 16 adjacent columns (128-byte row segments: full cache lines; 8 when L1 = 1024) with all L1 rows into LDS

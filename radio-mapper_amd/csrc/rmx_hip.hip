@@ -1180,6 +1180,12 @@ struct rmx_ctx {
     bool g_wfused = false;     // LDS-resident lengths, n_buoys <= 4: whole windows in g_win_fused (no spectra in HBM)
     const void* g_wf_fn[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [default plan][u8]
     size_t g_wf_lds[2] = {0, 0};           // [default plan]
+    bool g_wscr = false;       // 512 <= L <= 16384, any buoy count: whole windows in g_win_scr (spectra in a cache-resident scratch)
+    const void* g_ws_fn[2] = {nullptr, nullptr};   // [u8]
+    size_t g_ws_lds = 0;
+    int g_ws_thr = 0, g_ws_upw = 0, g_ws_grid = 0;
+    float4* g_ws_scratch = nullptr;
+    float2* g_tw_win = nullptr;            // W_L half table of that kernel
     const void* g_cols_inv_fn = nullptr;
     const void* g_cols_fwd_fn[2] = {nullptr, nullptr};   // [u8]
     const void* g_rows_inv_fn = nullptr;
@@ -1457,6 +1463,22 @@ static size_t gen_wfused_lds(int logR, bool tw_regs) {     // transform buffers 
     const int buf = logR == 9 ? gen::FusedPlan<9>::buf : logR == 10 ? gen::FusedPlan<10>::buf : logR == 11 ? gen::FusedPlan<11>::buf : gen::FusedPlan<12>::buf;
     return ((size_t)upw * buf + (size_t)(tw_regs ? 0 : gen::fused_tab_total(logR)) + 8) * 8;
 }
+template <bool U8>
+static const void* wscr_fn(int logR) {                      // g_win_scr<log2 L, uint8 input>
+    switch (logR) {
+        case 9: return (const void*)gen::g_win_scr<9, U8>;
+        case 10: return (const void*)gen::g_win_scr<10, U8>;
+        case 11: return (const void*)gen::g_win_scr<11, U8>;
+        case 12: return (const void*)gen::g_win_scr<12, U8>;
+        case 13: return (const void*)gen::g_win_scr<13, U8>;
+        default: return (const void*)gen::g_win_scr<14, U8>;
+    }
+}
+static void wscr_shape(int logR, int* thr, int* upw, size_t* lds) {
+#define RMX_WS(L) case L: *thr = gen::WinPlan<L>::thr; *upw = gen::WinPlan<L>::upw; *lds = gen::WinPlan<L>::lds_bytes; break;
+    switch (logR) { RMX_WS(9) RMX_WS(10) RMX_WS(11) RMX_WS(12) RMX_WS(13) default: RMX_WS(14) }
+#undef RMX_WS
+}
 static size_t gen_fused_lds(int R, bool tw_regs = false) {   // g_rows_fused: R/16 threads per row (tw_regs: no twiddle tables)
     int logR = 0;
     while ((1 << logR) < R) ++logR;
@@ -1567,6 +1589,31 @@ static int generic_init(rmx_ctx* c) {
             }
             RMX_HIP(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, flds));
         }
+    }
+    // any buoy count, 512 <= L <= 16384: whole windows in one persistent kernel, spectra in a per-workgroup scratch
+    // (RMX_WSCR=0: the two-kernel LDS path / the four-step path, which the Doppler search uses in any case)
+    c->g_wscr = !c->g_wfused && c->g_logL >= 9 && c->g_logL <= 14;
+    if (const char* e = getenv("RMX_WSCR")) c->g_wscr = c->g_wscr && atoi(e) != 0;
+    if (c->g_wscr) {
+        make_row_table(t, (int)L);
+        int rc = upload(c, &c->g_tw_win, t);
+        if (rc) return rc;
+        c->g_ws_fn[0] = wscr_fn<false>(c->g_logL);
+        c->g_ws_fn[1] = wscr_fn<true>(c->g_logL);
+        wscr_shape(c->g_logL, &c->g_ws_thr, &c->g_ws_upw, &c->g_ws_lds);
+        int per_cu = 1;
+        for (int u = 0; u < 2; ++u)
+            RMX_HIP(c, hipFuncSetAttribute(c->g_ws_fn[u], hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->g_ws_lds));
+        RMX_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, c->g_ws_fn[0], c->g_ws_thr, c->g_ws_lds));
+        if (per_cu < 1) per_cu = 1;
+        if (const char* e = getenv("RMX_WSCR_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= per_cu) per_cu = v; }
+        long grid = (long)c->n_cus * per_cu;
+        const long need = ((long)c->max_windows + c->g_ws_upw - 1) / c->g_ws_upw;
+        if (grid > need) grid = need;
+        c->g_ws_grid = (int)grid;
+        const size_t sbytes = (size_t)grid * c->g_ws_upw * c->n_buoys * L * 8;
+        RMX_HIP(c, hipMalloc((void**)&c->g_ws_scratch, sbytes));
+        c->scratch_bytes += sbytes;
     }
     // windows per chunk: spectra (B*L) + products (P*L), 8 bytes each, under 32 GiB of the 288 (cfg2's 64
     // windows of 2^20 samples are one chunk of 6.4 GB)
@@ -1747,8 +1794,23 @@ static int generic_pairs(rmx_ctx* c, int w0, int wc, int n_pairs, int* d_lag, fl
 
 static int generic_batch(rmx_ctx* c, const void* d_iq, int n_windows, int n_pairs, int* d_lag, float* d_frac,
                          float* d_peak, bool u8) {
-    int rc = generic_ensure(c, n_pairs, !c->g_wfused);
+    int rc = generic_ensure(c, n_pairs, !c->g_wfused && !c->g_wscr);
     if (rc) return rc;
+    if (c->g_wscr) {
+        const int logL = c->g_logL, hs = logL / 2;
+        const void* a_iq = d_iq;
+        float4* a_scr = c->g_ws_scratch;
+        const float2* a_tw = c->g_tw_win;
+        int a_nb = c->n_buoys, a_np = n_pairs;
+        long a_nw = n_windows, a_first = 0;
+        float a_fs = std::ldexp(1.0f, -hs), a_os = std::ldexp(1.0f, -(logL - 2 * hs));
+        const gen::GPair* a_pairs = c->g_pairs;
+        long grid = ((long)n_windows + c->g_ws_upw - 1) / c->g_ws_upw;
+        if (grid > c->g_ws_grid) grid = c->g_ws_grid;
+        void* args[] = {&a_iq, &a_scr, &a_tw, &a_nb, &a_nw, &a_first, &a_fs, &a_os, &a_pairs, &a_np, &d_lag, &d_frac, &d_peak};
+        RMX_HIP(c, hipLaunchKernel(c->g_ws_fn[u8 ? 1 : 0], dim3((unsigned)grid), dim3(c->g_ws_thr), args, c->g_ws_lds, c->stream));
+        return RMX_OK;
+    }
     if (c->g_wfused) {
         using namespace gen;
         const int logL = c->g_logL, B = c->n_buoys, hs = logL / 2;
@@ -1900,7 +1962,8 @@ void rmx_destroy(rmx_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     for (void* p : {(void*)c->g_tw, (void*)c->g_tw1, (void*)c->g_tw2, (void*)c->g_thi, (void*)c->g_tlo, (void*)c->g_spec,
-                    (void*)c->g_spec_r, (void*)c->g_prod, (void*)c->g_rec, (void*)c->g_halo, (void*)c->g_pairs})
+                    (void*)c->g_spec_r, (void*)c->g_prod, (void*)c->g_rec, (void*)c->g_halo, (void*)c->g_pairs,
+                    (void*)c->g_ws_scratch, (void*)c->g_tw_win})
         if (p) (void)hipFree(p);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     for (hipEvent_t e : c->copy_ev)
