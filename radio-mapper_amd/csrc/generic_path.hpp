@@ -50,6 +50,14 @@ __device__ __forceinline__ float2 g_cmulc(float2 a, float2 b) {   // a * conj(b)
     return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
 }
 
+// Exchange between two passes.  LOCAL: every butterfly of the reading pass takes its inputs from lanes of its own
+// wave (blocks of at most 64 x 16 elements: the threads of a block are consecutive) -- a wave's LDS instructions
+// execute in issue order, so the compiler-only fence is enough and no wave waits for another; else a barrier.
+template <bool LOCAL>
+__device__ __forceinline__ void xsync() {
+    if constexpr (LOCAL) wave_lds_order();
+    else __syncthreads();
+}
 // In-place transforms of R = 2^logR points held in LDS; tw[k] = W_R^k, k < R/2.  Up to FOUR radix-2 stages
 // are fused per pass: a radix-16 (8, 4, 2) butterfly in registers -- the blocks of fft_r16.hpp / win8.hpp -- so a
 // pass costs one LDS read and write of the data and one barrier per four stages (2048 points: 16 x 16 x 8, three
@@ -693,7 +701,7 @@ __device__ __forceinline__ void fft_dif_rest_to_regs(float2* x, const TW& tab, i
         dif_pass<P::MM, 0, 3>(LOGR, P::BM, tab.m, tid, 1 << (LOGR - 4), typename P::IOA{x}, nb);
     else
         dif_pass<P::MM, 0, 2>(LOGR, P::BM, tab + fused_tab_off(LOGR, P::BM), tid, 1 << (LOGR - 4), typename P::IOA{x}, nb);
-    __syncthreads();
+    xsync<true>();      // blocks of 2^BM <= 256 elements = 16 consecutive threads: inside a wave
     const auto h = nb.open(tid << 4);
 #pragma unroll
     for (int m = 0; m < 16; ++m) out[m] = h.ld(m);
@@ -713,14 +721,15 @@ __device__ __forceinline__ void fft_dit_inv_from_regs(float2* x, const TW& tab, 
     const auto h = nb.open(tid << 4);
 #pragma unroll
     for (int m = 0; m < 16; ++m) h.st(m, make_float2(v[m].y, v[m].x));
-    __syncthreads();
+    xsync<true>();                                  // neighbours -> middle pass: inside a wave
+    constexpr bool one_wave = (1 << (LOGR - 4)) <= 64;      // the whole row belongs to one wave
     if constexpr (std::is_same_v<TW, FusedTw>) {
         dit_pass<P::MM, 0, 3>(LOGR, P::BM, tab.m, tid, 1 << (LOGR - 4), nb, io);
-        __syncthreads();
+        xsync<one_wave>();
         dit_pass<P::M0, 0, 3>(LOGR, LOGR, tab.a, tid, 1 << (LOGR - 4), io, last);
     } else {
         dit_pass<P::MM, 0, 2>(LOGR, P::BM, tab + fused_tab_off(LOGR, P::BM), tid, 1 << (LOGR - 4), nb, io);
-        __syncthreads();
+        xsync<one_wave>();
         dit_pass<P::M0, 0, 2>(LOGR, LOGR, tab, tid, 1 << (LOGR - 4), io, last);
     }
 }
@@ -750,6 +759,7 @@ __global__ __launch_bounds__(kGThreads, 2) void g_rows_fused(const float2* __res
                                                           const GPair* __restrict__ pairs, int n_pairs) {
     extern __shared__ __attribute__((aligned(16))) char gsm[];
     constexpr int R = 1 << LOGR, tpr = R >> 4, upw = kGThreads / tpr;   // threads per row, (window, rib) units per workgroup
+    constexpr bool one_wave = tpr <= 64;                                // a row's threads sit in one wave: no workgroup barriers (xsync)
     using P = FusedPlan<LOGR>;
     constexpr int M0 = P::M0;                                           // stages of the forward rows' first pass
     constexpr int a = LOGR >> 1, n1 = 1 << a, n2 = R >> a;
@@ -807,17 +817,17 @@ __global__ __launch_bounds__(kGThreads, 2) void g_rows_fused(const float2* __res
             int tl = tid;                         // (opaque copy: keeps the passes' address arithmetic inside the loop)
             asm volatile("" : "+v"(tl));
             dif_first_from_regs<LOGR>(x, twl, tl, S[b]);
-            __syncthreads();
+            xsync<one_wave>();
             fft_dif_rest_to_regs<LOGR>(x, twl, tl, S[b]);
             __builtin_amdgcn_sched_barrier(0);    // (the last butterfly is not to be interleaved with the next first pass)
-            __syncthreads();                      // the next transform's first pass overwrites x
+            xsync<one_wave>();                    // the next transform's first pass overwrites x
         }
         // inverse of the product in v (input k of the first butterfly) and the twiddled store to pair slot q
         auto finish = [&](float2 (&v)[16], int q) {
             int tl = tid;
             asm volatile("" : "+v"(tl));
             fft_dit_inv_from_regs<LOGR>(x, twl, tl, v);
-            __syncthreads();
+            xsync<true>();                        // (the store loop reads back the thread's own outputs of the last pass: n = tid mod R/16)
             if (live) {
                 float2* row = prod + (((long)wl * n_pairs + q) * n_rows + rib0) * R;
 #pragma unroll 4
@@ -827,7 +837,7 @@ __global__ __launch_bounds__(kGThreads, 2) void g_rows_fused(const float2* __res
                     row[goff + (unsigned)n] = make_float2(r.x * scale, r.y * scale);
                 }
             }
-            __syncthreads();                      // x (and, behind the last pair, t1) are rewritten
+            xsync<one_wave>();                    // x (and, behind the last pair, t1) are rewritten
         };
         if constexpr (DEF) {
             // the default plan, (i, j) with i < j, i-major: the pair loop unrolled, every product's registers known at
@@ -891,6 +901,8 @@ __device__ __forceinline__ void group_argmax(float& v, int& k, float* sv, int* s
             const int ok = sk[g * NW + w];
             if (ov > v || (ov == v && ok < k)) { v = ov; k = ok; }
         }
+    } else {
+        wave_lds_order();       // the caller's tap reads follow the other lanes' |r|^2 stores
     }
 }
 __host__ __device__ constexpr int default_pair_code(int nb, int q) {     // i * nb + j of the q-th pair i < j, i-major
@@ -910,6 +922,7 @@ __global__ __launch_bounds__(kGThreads, 2) void g_win_fused(const void* __restri
                                                          float* __restrict__ peak) {
     extern __shared__ __attribute__((aligned(16))) char gsm[];
     constexpr int R = 1 << LOGR, N = R >> 1, tpr = R >> 4, upw = kGThreads / tpr;   // threads per window, windows per workgroup
+    constexpr bool one_wave = tpr <= 64;                                            // a window's threads sit in one wave
     using P = FusedPlan<LOGR>;
     constexpr int M0 = P::M0;
     const int g = threadIdx.x / tpr, tid = threadIdx.x % tpr;
@@ -962,12 +975,12 @@ __global__ __launch_bounds__(kGThreads, 2) void g_win_fused(const void* __restri
         int tl = tid;                         // (opaque copy: keeps the passes' address arithmetic inside the loop)
         asm volatile("" : "+v"(tl));
         dif_first_from_regs<LOGR>(x, twl, tl, S[b]);
-        __syncthreads();
+        xsync<one_wave>();
         fft_dif_rest_to_regs<LOGR>(x, twl, tl, S[b]);
 #pragma unroll
         for (int k = 0; k < 16; ++k) S[b][k] = make_float2(S[b][k].x * fwd_scale, S[b][k].y * fwd_scale);
         __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();                      // the next transform's first pass overwrites x
+        xsync<one_wave>();                    // the next transform's first pass overwrites x
     }
     const long obase = (first_window + w) * (long)n_pairs;
     // inverse of the product in v; the last pass keeps (max |r|^2, lowest 'full' index) per thread and leaves |r|^2
@@ -985,8 +998,7 @@ __global__ __launch_bounds__(kGThreads, 2) void g_win_fused(const void* __restri
             }
             x[P::IOA::pos(n)].x = m2;
         }));
-        __syncthreads();
-        group_argmax<tpr>(best, bk, sv, sk, tl, g);
+        group_argmax<tpr>(best, bk, sv, sk, tl, g);       // (its barrier, or wave order, also publishes the |r|^2 for the taps)
         if (tl == 0 && live) {
             const float b = sqrtf(best) * out_scale;
             float frac = 0.0f;
@@ -998,7 +1010,7 @@ __global__ __launch_bounds__(kGThreads, 2) void g_win_fused(const void* __restri
             lag_frac[obase + q] = frac;
             peak[obase + q] = b;
         }
-        __syncthreads();                      // x, sv are rewritten by the next pair
+        xsync<one_wave>();                    // x is rewritten by the next pair (sv: behind the next inverse's barrier)
     };
     if constexpr (DEF) {
         // the default plan, pair q = (i, j) with i < j, i-major: unrolled by pack expansion (a "#pragma unroll" loop nest
@@ -1043,12 +1055,16 @@ struct WinPlan {
     static constexpr int R = 1 << LOGR, tpr = R >> 4;
     static constexpr int ML = ((LOGR - 1) & 3) + 1, RADL = 1 << ML, NITL = 16 / RADL;   // the neighbour pass
     static constexpr int NP = (LOGR - ML) / 4;                                            // radix-16 passes, blocks LOGR, LOGR - 4, ..
-    static constexpr bool TW1REG = LOGR >= 12;                                            // first pass's twiddles in registers
+#ifndef RMX_WS_TWG_FROM
+#define RMX_WS_TWG_FROM 99
+#endif
+    static constexpr bool TW1REG = LOGR >= 12 && LOGR < RMX_WS_TWG_FROM;                  // first pass's twiddles in registers
+    static constexpr bool TW1GLOBAL = LOGR >= RMX_WS_TWG_FROM;                            // ... or read from the global table
     static constexpr int thr = tpr < kGThreads ? kGThreads : tpr, upw = thr / tpr;         // threads, windows per workgroup
     static constexpr int tab_off(int b) {                                                 // entries in front of pass b's LDS table
         int acc = 0;
         for (int c = LOGR; c > b; c -= 4)
-            if (!(c == LOGR && TW1REG)) acc += 15 << (c - 4);
+            if (!(c == LOGR && (TW1REG || TW1GLOBAL))) acc += 15 << (c - 4);
         return acc;
     }
     static constexpr int tab_total = tab_off(ML);
@@ -1064,6 +1080,9 @@ __global__ __launch_bounds__(WinPlan<LOGR>::thr) void g_win_scr(const void* __re
     extern __shared__ __attribute__((aligned(16))) char gsm[];
     using P = WinPlan<LOGR>;
     constexpr int R = P::R, N = R >> 1, tpr = P::tpr, upw = P::upw, ML = P::ML, RADL = P::RADL, NITL = P::NITL;
+    // the exchange on the small side of the radix-16 pass over blocks of 2^b is wave-local when those blocks' 2^(b-4)
+    // threads fit a wave (b <= 10): at L = 16384 only the pass over the whole window needs workgroup barriers
+    constexpr bool one_wave = tpr <= 64;
     const int g = threadIdx.x / tpr, tid = threadIdx.x % tpr;
     float2* x = reinterpret_cast<float2*>(gsm) + g * lp(R);
     float2* tab = reinterpret_cast<float2*>(gsm) + upw * lp(R);
@@ -1075,7 +1094,7 @@ __global__ __launch_bounds__(WinPlan<LOGR>::thr) void g_win_scr(const void* __re
             for (int e = threadIdx.x; e < 15 * q; e += P::thr)
                 tab[off + e] = tw_full(tw, ((e & (q - 1)) << (LOGR - b)) * ((e >> (b - 4)) + 1), R >> 1);
         };
-        if constexpr (!P::TW1REG) build(std::integral_constant<int, LOGR>{});
+        if constexpr (!P::TW1REG && !P::TW1GLOBAL) build(std::integral_constant<int, LOGR>{});
         if constexpr (P::NP >= 2) build(std::integral_constant<int, LOGR - 4>{});
         if constexpr (P::NP >= 3) build(std::integral_constant<int, LOGR - 8>{});
     }
@@ -1118,20 +1137,21 @@ __global__ __launch_bounds__(WinPlan<LOGR>::thr) void g_win_scr(const void* __re
                 for (int k = 1; k < 16; ++k) {
                     float2 wk;
                     if constexpr (P::TW1REG) wk = tw1.w[k - 1];
+                    else if constexpr (P::TW1GLOBAL) wk = tw_full(tw, tid * k, R >> 1);
                     else wk = tab[(k - 1) * tpr + tid];
                     hd.st(brev_m<4>(k) * tpr, g_cmul(v[k], wk));
                 }
             }
-            __syncthreads();
+            xsync<one_wave>();
             if constexpr (P::NP >= 2) {
                 constexpr int bb = LOGR - 4, off = P::tab_off(bb);
                 dif_pass<4, 0, 2>(LOGR, bb, tab + off, tid, tpr, lds, lds);
-                __syncthreads();
+                xsync<(bb <= 10)>();
             }
             if constexpr (P::NP >= 3) {
                 constexpr int bb = LOGR - 8, off = P::tab_off(bb);
                 dif_pass<4, 0, 2>(LOGR, bb, tab + off, tid, tpr, lds, lds);
-                __syncthreads();
+                xsync<(bb <= 10)>();
             }
             {   // the thread's 16 neighbours: 16 / 2^ML butterflies, outputs stay in registers (butterfly order)
                 const auto h = lds.open(tid << 4);
@@ -1149,7 +1169,7 @@ __global__ __launch_bounds__(WinPlan<LOGR>::thr) void g_win_scr(const void* __re
             for (int kk = 0; kk < 8; ++kk)
                 scr[(long)(b * 8 + kk) * tpr] = make_float4(v[2 * kk].x * fwd_scale, v[2 * kk].y * fwd_scale,
                                                              v[2 * kk + 1].x * fwd_scale, v[2 * kk + 1].y * fwd_scale);
-            __syncthreads();                      // the next transform's first pass overwrites x
+            xsync<one_wave>();                    // the next transform's first pass overwrites x
         }
         const long obase = (first_window + w) * (long)n_pairs;
         for (int q = 0; q < n_pairs; ++q) {
@@ -1160,6 +1180,9 @@ __global__ __launch_bounds__(WinPlan<LOGR>::thr) void g_win_scr(const void* __re
                 const float4 a = scr[(long)(pr.j * 8 + kk) * tpr], c = scr[(long)(pr.i * 8 + kk) * tpr];
                 v[2 * kk] = g_cmulc(make_float2(a.x, a.y), make_float2(c.x, c.y));
                 v[2 * kk + 1] = g_cmulc(make_float2(a.z, a.w), make_float2(c.z, c.w));
+                if constexpr (P::thr == 1024) {   // (128 VGPRs: two halves of the loads, not all sixteen in flight at once)
+                    if (kk == 3) __builtin_amdgcn_sched_barrier(0);
+                }
             }
             {   // inverse, first pass: the same neighbour butterflies ((im, re)-swapped data: swap o DFT o swap = conj DFT)
                 const auto h = lds.open(tid << 4);
@@ -1173,17 +1196,17 @@ __global__ __launch_bounds__(WinPlan<LOGR>::thr) void g_win_scr(const void* __re
                     for (int m = 0; m < RADL; ++m) h.st(it * RADL + m, make_float2(t[m].y, t[m].x));
                 }
             }
-            __syncthreads();
             if constexpr (P::NP >= 3) {
                 constexpr int bb = LOGR - 8, off = P::tab_off(bb);
+                xsync<(bb <= 10)>();
                 dit_pass<4, 0, 2>(LOGR, bb, tab + off, tid, tpr, lds, lds);
-                __syncthreads();
             }
             if constexpr (P::NP >= 2) {
                 constexpr int bb = LOGR - 4, off = P::tab_off(bb);
+                xsync<(bb <= 10)>();
                 dit_pass<4, 0, 2>(LOGR, bb, tab + off, tid, tpr, lds, lds);
-                __syncthreads();
             }
+            xsync<one_wave>();                    // the pass over the whole window reads every wave's blocks
             float best = -1.0f;
             int bk = 0x7fffffff;
             const auto scan = make_dst([&](int E0, int off, float2 e) __attribute__((always_inline)) {
@@ -1196,9 +1219,9 @@ __global__ __launch_bounds__(WinPlan<LOGR>::thr) void g_win_scr(const void* __re
                 x[lp(n)].x = m2;
             });
             if constexpr (P::TW1REG) dit_pass<4, 0, 3>(LOGR, LOGR, tw1, tid, tpr, lds, scan);
+            else if constexpr (P::TW1GLOBAL) dit_pass<4, 0, 0>(LOGR, LOGR, tw, tid, tpr, lds, scan);
             else dit_pass<4, 0, 2>(LOGR, LOGR, tab, tid, tpr, lds, scan);
-            __syncthreads();
-            group_argmax<tpr>(best, bk, sv, sk, tid, g);
+            group_argmax<tpr>(best, bk, sv, sk, tid, g);      // (its barrier, or wave order, also publishes the |r|^2 for the taps)
             if (tid == 0 && live) {
                 const float bpk = sqrtf(best) * out_scale;
                 float frac = 0.0f;
@@ -1210,7 +1233,7 @@ __global__ __launch_bounds__(WinPlan<LOGR>::thr) void g_win_scr(const void* __re
                 lag_frac[obase + q] = frac;
                 peak[obase + q] = bpk;
             }
-            __syncthreads();                      // x, sv are rewritten
+            xsync<one_wave>();                    // x is rewritten (sv: behind the next inverse's barrier)
         }
     }
 }

@@ -649,6 +649,35 @@ def test_whole_window_kernel_by_length(xc, N, B, monkeypatch):
     assert np.array_equal(ui, li) and np.all(np.abs(uf - lf) <= TOL) and np.allclose(up, pk, rtol=1e-5)
 
 
+@pytest.mark.parametrize("N,B", [(256, 5), (512, 8), (1024, 6), (2048, 8), (2048, 16), (8192, 3), (8192, 8), (8192, 2)])
+def test_whole_window_scratch_kernel_by_length(xc, N, B, monkeypatch):
+    """Every other shape with 512 <= L <= 16384 -- more than four buoys, or N = 8192 (the capture length of
+    iq_stream_client.py:459) -- runs whole windows in one persistent kernel with the spectra in a per-workgroup
+    scratch (g_win_scr, compiled per length; at L = 16384 one 136 KiB transform per CU, 1024 threads): against the
+    oracle on complex64 and raw uint8 input, more windows than one pass of the grid on the small lengths, a custom
+    pair list (reversed, repeated, autocorrelation), and the previous path (RMX_WSCR=0: two-kernel LDS path or
+    four-step) on the same input."""
+    W = 700 if N <= 512 else (5 if N >= 8192 else 9)
+    iq, _, raw = rm.synth.make_windows(W, B, N, 2.4e6, seed=800 + B + N % 977, return_u8=True)
+    sub = slice(0, min(W, 12))                                   # literal oracle on the first windows, the rest by consistency
+    ri, rf, rp = orc.xcorr_batch_literal(iq[sub])
+    margin = np.array([[orc.peak_margin(iq[w, i], iq[w, j]) for (i, j) in orc.pair_list(B)] for w in range(ri.shape[0])])
+    custom = np.array([(B - 1, 0), (0, 1), (1, 1), (0, 1)], np.int32)
+    with xc.XcorrEngine(B, N, W) as eng:
+        li, lf, pk = eng.correlate(iq)
+        l8, f8, p8 = eng.correlate(raw)
+        ci, cf, cp = eng.correlate(iq[sub], custom)
+    _assert_parity(li[sub], lf[sub], pk[sub], ri, rf, rp, margin)
+    assert np.array_equal(li, l8) and np.array_equal(lf, f8) and np.array_equal(pk, p8)
+    oi, of_, op = orc.xcorr_batch_literal(iq[sub], custom)
+    _assert_parity(ci, cf, cp, oi, of_, op)
+    monkeypatch.setenv("RMX_WSCR", "0")
+    monkeypatch.setenv("RMX_WFUSED", "0")
+    with xc.XcorrEngine(B, N, W) as eng:
+        ui, uf, up = eng.correlate(iq)
+    assert np.array_equal(ui, li) and np.all(np.abs(uf - lf) <= TOL) and np.allclose(up, pk, rtol=1e-5)
+
+
 @pytest.mark.parametrize("case", range(12))
 def test_seeded_random_shapes_and_pair_lists(xc, case):
     """Seeded sweep over (buoys, window length, windows, pair list): every kernel family gets shapes nobody
