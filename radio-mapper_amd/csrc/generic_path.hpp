@@ -387,6 +387,17 @@ __device__ __forceinline__ void lds_dit_inv(float2* x, int logR, const float2* _
 __device__ __forceinline__ int full_index(int m, int N) { return m < N ? m + N - 1 : (m == N ? -1 : m - N - 1); }
 __device__ __forceinline__ int circ_index(int k, int N) { return k >= N - 1 ? k - (N - 1) : k + N + 1; }
 
+// One output of an inverse's last pass into a thread's running (max |r|^2, lowest 'full' index), branch-free: the
+// index is n + N - 1 below N and n - N - 1 above (n == N, lag -N, is not part of the 'full' output: its value is
+// replaced by -2, which never beats the -1 the search starts from).  With n = tid + a multiple of R / 16 the
+// comparisons against N fold at compile time for all but one element.
+__device__ __forceinline__ void scan_update(float& best, int& bk, float m2, int n, int N) {
+    const int k = n < N ? n + (N - 1) : n - (N + 1);
+    const float v = n == N ? -2.0f : m2;
+    const bool better = (v > best) | ((v == best) & (k < bk));      // (bitwise: short-circuit forms become branches)
+    best = better ? v : best;
+    bk = better ? k : bk;
+}
 // workgroup argmax of (value, lowest index): every thread passes its best candidate
 __device__ __forceinline__ void block_argmax(float& v, int& k, float* sv, int* sk, int tid, int nthr) {
     sv[tid] = v;
@@ -992,10 +1003,7 @@ __global__ __launch_bounds__(kGThreads, 2) void g_win_fused(const void* __restri
         fft_dit_inv_from_regs<LOGR>(x, twl, tl, v, make_dst([&](int E0, int off, float2 e) __attribute__((always_inline)) {
             const int n = E0 + off;
             const float m2 = e.x * e.x + e.y * e.y;
-            if (m2 >= best) {
-                const int k = full_index(n, N);
-                if (k >= 0 && (m2 > best || k < bk)) { best = m2; bk = k; }
-            }
+            scan_update(best, bk, m2, n, N);
             x[P::IOA::pos(n)].x = m2;
         }));
         group_argmax<tpr>(best, bk, sv, sk, tl, g);       // (its barrier, or wave order, also publishes the |r|^2 for the taps)
@@ -1070,6 +1078,111 @@ struct WinPlan {
     static constexpr int tab_total = tab_off(ML);
     static constexpr size_t lds_bytes = ((size_t)upw * lp(R) + tab_total + 16) * 8;
 };
+// The transforms of those kernels: one window's R / 16 threads, buffer x (lp() layout), the passes' twiddles
+template <int LOGR>
+struct WinXf {
+    using P = WinPlan<LOGR>;
+    static constexpr int R = P::R, tpr = P::tpr, ML = P::ML, RADL = P::RADL, NITL = P::NITL;
+    // the exchange on the small side of the radix-16 pass over blocks of 2^b is wave-local when those blocks' 2^(b-4)
+    // threads fit a wave (b <= 10): at L = 16384 only the pass over the whole window needs workgroup barriers
+    static constexpr bool one_wave = tpr <= 64;
+    float2* x;
+    float2* tab;
+    const float2* __restrict__ tw;
+    TwRegs tw1;
+    int tid;
+    // tables [k = 1..15][l < q]: W_R^(l k 2^(LOGR - b)), consecutive lanes read consecutive entries; all threads of the
+    // workgroup; the caller's barrier follows
+    __device__ __forceinline__ void setup() {
+        auto build = [&](auto bc) __attribute__((always_inline)) {
+            constexpr int b = decltype(bc)::value, q = 1 << (b - 4), off = P::tab_off(b);
+            for (int e = threadIdx.x; e < 15 * q; e += P::thr)
+                tab[off + e] = tw_full(tw, ((e & (q - 1)) << (LOGR - b)) * ((e >> (b - 4)) + 1), R >> 1);
+        };
+        if constexpr (!P::TW1REG && !P::TW1GLOBAL) build(std::integral_constant<int, LOGR>{});
+        if constexpr (P::NP >= 2) build(std::integral_constant<int, LOGR - 4>{});
+        if constexpr (P::NP >= 3) build(std::integral_constant<int, LOGR - 8>{});
+        if constexpr (P::TW1REG) {
+#pragma unroll
+            for (int k = 1; k < 16; ++k) tw1.w[k - 1] = tw_full(tw, tid * k, R >> 1);
+        }
+    }
+    // forward: v[m] = element tid + m R/16 (m >= 8: the zero-padded half, literal zeros) -> the spectrum in the register
+    // order of the last butterflies: v[it 2^ML + k] is the bin at position 16 tid + it 2^ML + bitrev_ML(k) of the
+    // bit-reversed spectrum.  Ends with the exchange that lets the next transform overwrite x.
+    __device__ __forceinline__ void fwd(float2 (&v)[16]) const {
+        const LdsIO lds{x};
+        {   // first pass: the whole window
+            dft16(v);
+            const auto hd = lds.open(tid);
+            hd.st(0, v[0]);
+#pragma unroll
+            for (int k = 1; k < 16; ++k) {
+                float2 wk;
+                if constexpr (P::TW1REG) wk = tw1.w[k - 1];
+                else if constexpr (P::TW1GLOBAL) wk = tw_full(tw, tid * k, R >> 1);
+                else wk = tab[(k - 1) * tpr + tid];
+                hd.st(brev_m<4>(k) * tpr, g_cmul(v[k], wk));
+            }
+        }
+        xsync<one_wave>();
+        if constexpr (P::NP >= 2) {
+            constexpr int bb = LOGR - 4, off = P::tab_off(bb);
+            dif_pass<4, 0, 2>(LOGR, bb, tab + off, tid, tpr, lds, lds);
+            xsync<(bb <= 10)>();
+        }
+        if constexpr (P::NP >= 3) {
+            constexpr int bb = LOGR - 8, off = P::tab_off(bb);
+            dif_pass<4, 0, 2>(LOGR, bb, tab + off, tid, tpr, lds, lds);
+            xsync<(bb <= 10)>();
+        }
+        {   // the thread's 16 neighbours: 16 / 2^ML butterflies, outputs stay in registers (butterfly order)
+            const auto h = lds.open(tid << 4);
+#pragma unroll
+            for (int it = 0; it < NITL; ++it) {
+                float2 t[RADL];
+#pragma unroll
+                for (int m = 0; m < RADL; ++m) t[m] = h.ld(it * RADL + m);
+                dft_reg<RADL>(t);
+#pragma unroll
+                for (int m = 0; m < RADL; ++m) v[it * RADL + m] = t[m];
+            }
+        }
+        xsync<one_wave>();                    // the next transform's first pass overwrites x
+    }
+    // inverse (unnormalised) of the product in v (same register order); the last pass hands every output (natural index
+    // n) to `scan`
+    template <class Scan>
+    __device__ __forceinline__ void inv(float2 (&v)[16], const Scan& scan) const {
+        const LdsIO lds{x};
+        {   // first pass: the same neighbour butterflies ((im, re)-swapped data: swap o DFT o swap = conj DFT)
+            const auto h = lds.open(tid << 4);
+#pragma unroll
+            for (int it = 0; it < NITL; ++it) {
+                float2 t[RADL];
+#pragma unroll
+                for (int k = 0; k < RADL; ++k) t[k] = make_float2(v[it * RADL + k].y, v[it * RADL + k].x);
+                dft_reg<RADL>(t);
+#pragma unroll
+                for (int m = 0; m < RADL; ++m) h.st(it * RADL + m, make_float2(t[m].y, t[m].x));
+            }
+        }
+        if constexpr (P::NP >= 3) {
+            constexpr int bb = LOGR - 8, off = P::tab_off(bb);
+            xsync<(bb <= 10)>();
+            dit_pass<4, 0, 2>(LOGR, bb, tab + off, tid, tpr, lds, lds);
+        }
+        if constexpr (P::NP >= 2) {
+            constexpr int bb = LOGR - 4, off = P::tab_off(bb);
+            xsync<(bb <= 10)>();
+            dit_pass<4, 0, 2>(LOGR, bb, tab + off, tid, tpr, lds, lds);
+        }
+        xsync<one_wave>();                    // the pass over the whole window reads every wave's blocks
+        if constexpr (P::TW1REG) dit_pass<4, 0, 3>(LOGR, LOGR, tw1, tid, tpr, lds, scan);
+        else if constexpr (P::TW1GLOBAL) dit_pass<4, 0, 0>(LOGR, LOGR, tw, tid, tpr, lds, scan);
+        else dit_pass<4, 0, 2>(LOGR, LOGR, tab, tid, tpr, lds, scan);
+    }
+};
 template <int LOGR, bool U8>
 __global__ __launch_bounds__(WinPlan<LOGR>::thr) void g_win_scr(const void* __restrict__ iq, float4* __restrict__ scratch,
                                                              const float2* __restrict__ tw, int n_buoys, long n_windows,
@@ -1079,32 +1192,16 @@ __global__ __launch_bounds__(WinPlan<LOGR>::thr) void g_win_scr(const void* __re
                                                              float* __restrict__ peak) {
     extern __shared__ __attribute__((aligned(16))) char gsm[];
     using P = WinPlan<LOGR>;
-    constexpr int R = P::R, N = R >> 1, tpr = P::tpr, upw = P::upw, ML = P::ML, RADL = P::RADL, NITL = P::NITL;
-    // the exchange on the small side of the radix-16 pass over blocks of 2^b is wave-local when those blocks' 2^(b-4)
-    // threads fit a wave (b <= 10): at L = 16384 only the pass over the whole window needs workgroup barriers
+    constexpr int R = P::R, N = R >> 1, tpr = P::tpr, upw = P::upw;
     constexpr bool one_wave = tpr <= 64;
     const int g = threadIdx.x / tpr, tid = threadIdx.x % tpr;
     float2* x = reinterpret_cast<float2*>(gsm) + g * lp(R);
     float2* tab = reinterpret_cast<float2*>(gsm) + upw * lp(R);
     float* sv = reinterpret_cast<float*>(tab + P::tab_total);
     int* sk = reinterpret_cast<int*>(sv + 16);
-    {   // the passes' tables [k = 1..15][l < q]: W_R^(l k 2^(LOGR - b)), consecutive lanes read consecutive entries
-        auto build = [&](auto bc) __attribute__((always_inline)) {
-            constexpr int b = decltype(bc)::value, q = 1 << (b - 4), off = P::tab_off(b);
-            for (int e = threadIdx.x; e < 15 * q; e += P::thr)
-                tab[off + e] = tw_full(tw, ((e & (q - 1)) << (LOGR - b)) * ((e >> (b - 4)) + 1), R >> 1);
-        };
-        if constexpr (!P::TW1REG && !P::TW1GLOBAL) build(std::integral_constant<int, LOGR>{});
-        if constexpr (P::NP >= 2) build(std::integral_constant<int, LOGR - 4>{});
-        if constexpr (P::NP >= 3) build(std::integral_constant<int, LOGR - 8>{});
-    }
-    TwRegs tw1;
-    if constexpr (P::TW1REG) {
-#pragma unroll
-        for (int k = 1; k < 16; ++k) tw1.w[k - 1] = tw_full(tw, tid * k, R >> 1);
-    }
+    WinXf<LOGR> xf{x, tab, tw, {}, tid};
+    xf.setup();
     __syncthreads();
-    const LdsIO lds{x};
     float4* scr = scratch + ((long)blockIdx.x * upw + g) * n_buoys * (8L * tpr) + tid;
     for (long blk = blockIdx.x; blk * upw < n_windows; blk += gridDim.x) {
         const long w = blk * upw + g;
@@ -1129,47 +1226,11 @@ __global__ __launch_bounds__(WinPlan<LOGR>::thr) void g_win_scr(const void* __re
 #pragma unroll
             for (int m = 0; m < 8; ++m) { v[m] = nx[m]; v[m + 8] = make_float2(0.f, 0.f); }   // the zero-padded half: literal zeros
             if (b + 1 < n_buoys) load_in(nx, b + 1);                                           // travels during this transform
-            {   // first pass: the whole window, elements tid + m R/16
-                dft16(v);
-                const auto hd = lds.open(tid);
-                hd.st(0, v[0]);
-#pragma unroll
-                for (int k = 1; k < 16; ++k) {
-                    float2 wk;
-                    if constexpr (P::TW1REG) wk = tw1.w[k - 1];
-                    else if constexpr (P::TW1GLOBAL) wk = tw_full(tw, tid * k, R >> 1);
-                    else wk = tab[(k - 1) * tpr + tid];
-                    hd.st(brev_m<4>(k) * tpr, g_cmul(v[k], wk));
-                }
-            }
-            xsync<one_wave>();
-            if constexpr (P::NP >= 2) {
-                constexpr int bb = LOGR - 4, off = P::tab_off(bb);
-                dif_pass<4, 0, 2>(LOGR, bb, tab + off, tid, tpr, lds, lds);
-                xsync<(bb <= 10)>();
-            }
-            if constexpr (P::NP >= 3) {
-                constexpr int bb = LOGR - 8, off = P::tab_off(bb);
-                dif_pass<4, 0, 2>(LOGR, bb, tab + off, tid, tpr, lds, lds);
-                xsync<(bb <= 10)>();
-            }
-            {   // the thread's 16 neighbours: 16 / 2^ML butterflies, outputs stay in registers (butterfly order)
-                const auto h = lds.open(tid << 4);
-#pragma unroll
-                for (int it = 0; it < NITL; ++it) {
-                    float2 t[RADL];
-#pragma unroll
-                    for (int m = 0; m < RADL; ++m) t[m] = h.ld(it * RADL + m);
-                    dft_reg<RADL>(t);
-#pragma unroll
-                    for (int m = 0; m < RADL; ++m) v[it * RADL + m] = t[m];
-                }
-            }
+            xf.fwd(v);
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk)
                 scr[(long)(b * 8 + kk) * tpr] = make_float4(v[2 * kk].x * fwd_scale, v[2 * kk].y * fwd_scale,
                                                              v[2 * kk + 1].x * fwd_scale, v[2 * kk + 1].y * fwd_scale);
-            xsync<one_wave>();                    // the next transform's first pass overwrites x
         }
         const long obase = (first_window + w) * (long)n_pairs;
         for (int q = 0; q < n_pairs; ++q) {
@@ -1180,47 +1241,15 @@ __global__ __launch_bounds__(WinPlan<LOGR>::thr) void g_win_scr(const void* __re
                 const float4 a = scr[(long)(pr.j * 8 + kk) * tpr], c = scr[(long)(pr.i * 8 + kk) * tpr];
                 v[2 * kk] = g_cmulc(make_float2(a.x, a.y), make_float2(c.x, c.y));
                 v[2 * kk + 1] = g_cmulc(make_float2(a.z, a.w), make_float2(c.z, c.w));
-                if constexpr (P::thr == 1024) {   // (128 VGPRs: two halves of the loads, not all sixteen in flight at once)
-                    if (kk == 3) __builtin_amdgcn_sched_barrier(0);
-                }
             }
-            {   // inverse, first pass: the same neighbour butterflies ((im, re)-swapped data: swap o DFT o swap = conj DFT)
-                const auto h = lds.open(tid << 4);
-#pragma unroll
-                for (int it = 0; it < NITL; ++it) {
-                    float2 t[RADL];
-#pragma unroll
-                    for (int k = 0; k < RADL; ++k) t[k] = make_float2(v[it * RADL + k].y, v[it * RADL + k].x);
-                    dft_reg<RADL>(t);
-#pragma unroll
-                    for (int m = 0; m < RADL; ++m) h.st(it * RADL + m, make_float2(t[m].y, t[m].x));
-                }
-            }
-            if constexpr (P::NP >= 3) {
-                constexpr int bb = LOGR - 8, off = P::tab_off(bb);
-                xsync<(bb <= 10)>();
-                dit_pass<4, 0, 2>(LOGR, bb, tab + off, tid, tpr, lds, lds);
-            }
-            if constexpr (P::NP >= 2) {
-                constexpr int bb = LOGR - 4, off = P::tab_off(bb);
-                xsync<(bb <= 10)>();
-                dit_pass<4, 0, 2>(LOGR, bb, tab + off, tid, tpr, lds, lds);
-            }
-            xsync<one_wave>();                    // the pass over the whole window reads every wave's blocks
             float best = -1.0f;
             int bk = 0x7fffffff;
-            const auto scan = make_dst([&](int E0, int off, float2 e) __attribute__((always_inline)) {
+            xf.inv(v, make_dst([&](int E0, int off, float2 e) __attribute__((always_inline)) {
                 const int n = E0 + off;
                 const float m2 = e.x * e.x + e.y * e.y;
-                if (m2 >= best) {
-                    const int k = full_index(n, N);
-                    if (k >= 0 && (m2 > best || k < bk)) { best = m2; bk = k; }
-                }
+                scan_update(best, bk, m2, n, N);
                 x[lp(n)].x = m2;
-            });
-            if constexpr (P::TW1REG) dit_pass<4, 0, 3>(LOGR, LOGR, tw1, tid, tpr, lds, scan);
-            else if constexpr (P::TW1GLOBAL) dit_pass<4, 0, 0>(LOGR, LOGR, tw, tid, tpr, lds, scan);
-            else dit_pass<4, 0, 2>(LOGR, LOGR, tab, tid, tpr, lds, scan);
+            }));
             group_argmax<tpr>(best, bk, sv, sk, tid, g);      // (its barrier, or wave order, also publishes the |r|^2 for the taps)
             if (tid == 0 && live) {
                 const float bpk = sqrtf(best) * out_scale;

@@ -41,8 +41,9 @@ def timeit(B, N, W, on, wf="1"):
     return sorted(ts)[len(ts) // 2]
 
 bad = 0
+logNs = [int(a) for a in sys.argv[1:] if a.isdigit()] or [8, 9, 10, 11, 13]
 if "time" not in sys.argv:
-  for logN in (8, 9, 10, 11, 13):
+  for logN in logNs:
     for B in (2, 3, 5, 8):
         N, W = 1 << logN, 11
         iq, delays, raw = synth.make_windows(W, B, N, 10e6, seed=200 + logN + B, return_u8=True)
@@ -54,7 +55,9 @@ if "time" not in sys.argv:
             ok = dl == 0 and df < 1e-5 and dp < 1e-5
             print(f"N=2^{logN} B={B} {name}: lag mismatches {dl} dfrac {df:.2e} dpeak {dp:.2e} {'ok' if ok else 'MISMATCH'}", flush=True)
             bad += not ok
-for B, N, W in ((8, 2048, 2048), (8, 1024, 4096), (8, 256, 8192), (3, 8192, 1024), (8, 8192, 512), (16, 2048, 1024), (3, 2048, 4096), (5, 8192, 512)):
+shapes = ((8, 2048, 2048), (8, 1024, 4096), (8, 256, 8192), (3, 8192, 1024), (8, 8192, 512), (16, 2048, 1024), (3, 2048, 4096), (5, 8192, 512))
+for B, N, W in shapes:
+    if (N.bit_length() - 1) not in logNs and "all" not in sys.argv: continue
     tf, tu = timeit(B, N, W, True, "0"), timeit(B, N, W, False)
     alg = W * (B * (B - 1) // 2) * (16 * N + 12)
     print(f"B={B} N={N} W={W}: g_win_scr {tf:.3f} ms ({alg / tf / 1e6 / 8000 * 100:.1f} % of 8 TB/s)   before {tu:.3f} ms ({alg / tu / 1e6 / 8000 * 100:.1f} %)", flush=True)
