@@ -1181,6 +1181,7 @@ struct rmx_ctx {
     const void* g_wf_fn[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [default plan][u8]
     size_t g_wf_lds[2] = {0, 0};           // [default plan]
     bool g_wscr = false;       // 512 <= L <= 16384, any buoy count: whole windows in g_win_scr (spectra in a cache-resident scratch)
+    bool g_wscr_always = false;
     const void* g_ws_fn[2] = {nullptr, nullptr};   // [u8]
     size_t g_ws_lds = 0;
     int g_ws_thr = 0, g_ws_upw = 0, g_ws_grid = 0;
@@ -1593,7 +1594,10 @@ static int generic_init(rmx_ctx* c) {
     // any buoy count, 512 <= L <= 16384: whole windows in one persistent kernel, spectra in a per-workgroup scratch
     // (RMX_WSCR=0: the two-kernel LDS path / the four-step path, which the Doppler search uses in any case)
     c->g_wscr = !c->g_wfused && c->g_logL >= 9 && c->g_logL <= 14;
-    if (const char* e = getenv("RMX_WSCR")) c->g_wscr = c->g_wscr && atoi(e) != 0;
+    if (const char* e = getenv("RMX_WSCR")) {          // 0: never, 2: also for batches that do not fill the chip (tests)
+        c->g_wscr = c->g_wscr && atoi(e) != 0;
+        c->g_wscr_always = atoi(e) == 2;
+    }
     if (c->g_wscr) {
         make_row_table(t, (int)L);
         int rc = upload(c, &c->g_tw_win, t);
@@ -1794,9 +1798,13 @@ static int generic_pairs(rmx_ctx* c, int w0, int wc, int n_pairs, int* d_lag, fl
 
 static int generic_batch(rmx_ctx* c, const void* d_iq, int n_windows, int n_pairs, int* d_lag, float* d_frac,
                          float* d_peak, bool u8) {
-    int rc = generic_ensure(c, n_pairs, !c->g_wfused && !c->g_wscr);
+    // g_win_scr runs a window's B + P transforms one after the other in one workgroup: batches that leave most of the chip
+    // without a workgroup are better off in the per-transform kernels below (8 buoys x 8 windows of 8192: 0.32 vs 0.05 ms;
+    // measured crossovers at 0.5 .. 0.8 workgroups per CU)
+    const bool use_wscr = c->g_wscr && (c->g_wscr_always || ((long)n_windows + c->g_ws_upw - 1) / c->g_ws_upw >= 3L * c->n_cus / 4);
+    int rc = generic_ensure(c, n_pairs, !c->g_wfused && !use_wscr);
     if (rc) return rc;
-    if (c->g_wscr) {
+    if (use_wscr) {
         const int logL = c->g_logL, hs = logL / 2;
         const void* a_iq = d_iq;
         float4* a_scr = c->g_ws_scratch;

@@ -663,6 +663,7 @@ def test_whole_window_scratch_kernel_by_length(xc, N, B, monkeypatch):
     ri, rf, rp = orc.xcorr_batch_literal(iq[sub])
     margin = np.array([[orc.peak_margin(iq[w, i], iq[w, j]) for (i, j) in orc.pair_list(B)] for w in range(ri.shape[0])])
     custom = np.array([(B - 1, 0), (0, 1), (1, 1), (0, 1)], np.int32)
+    monkeypatch.setenv("RMX_WSCR", "2")        # (a few windows would not fill the chip: the engine would pick the per-transform kernels)
     with xc.XcorrEngine(B, N, W) as eng:
         li, lf, pk = eng.correlate(iq)
         l8, f8, p8 = eng.correlate(raw)
