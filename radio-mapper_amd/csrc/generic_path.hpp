@@ -1242,14 +1242,24 @@ __global__ __launch_bounds__(WinPlan<LOGR>::thr) void g_win_scr(const void* __re
                 v[2 * kk] = g_cmulc(make_float2(a.x, a.y), make_float2(c.x, c.y));
                 v[2 * kk + 1] = g_cmulc(make_float2(a.z, a.w), make_float2(c.z, c.w));
             }
-            float best = -1.0f;
-            int bk = 0x7fffffff;
+            // the last pass hands thread tid its outputs n = tid + s R/16, s = 0 .. 15: |r|^2 into mg[s] and into the buffer (taps)
+            float mg[16];
             xf.inv(v, make_dst([&](int E0, int off, float2 e) __attribute__((always_inline)) {
-                const int n = E0 + off;
                 const float m2 = e.x * e.x + e.y * e.y;
-                scan_update(best, bk, m2, n, N);
-                x[lp(n)].x = m2;
+                mg[off / tpr] = m2;                           // (off = s R/16 is a constant once the pass is unrolled)
+                x[lp(E0 + off)].x = m2;
             }));
+            // the thread's (max, lowest 'full' index): 'full' index n - N - 1 for s >= 8 (lag -N itself, n = N: thread 0, s = 8,
+            // is not part of the output), n + N - 1 for s < 8 -- ascending in the order s = 8 .. 15, 0 .. 7
+            if (tid == 0) mg[8] = -2.0f;
+            float best = fmaxf(fmaxf(fmaxf(fmaxf(mg[0], mg[1]), fmaxf(mg[2], mg[3])), fmaxf(fmaxf(mg[4], mg[5]), fmaxf(mg[6], mg[7]))),
+                               fmaxf(fmaxf(fmaxf(mg[8], mg[9]), fmaxf(mg[10], mg[11])), fmaxf(fmaxf(mg[12], mg[13]), fmaxf(mg[14], mg[15]))));
+            int ssel = 7;                                     // lowest-index slot holding the max: later assignments win
+#pragma unroll
+            for (int s = 6; s >= 0; --s) ssel = mg[s] == best ? s : ssel;
+#pragma unroll
+            for (int s = 15; s >= 8; --s) ssel = mg[s] == best ? s : ssel;
+            int bk = tid + (ssel & 7) * tpr + (ssel >= 8 ? -1 : N - 1);
             group_argmax<tpr>(best, bk, sv, sk, tid, g);      // (its barrier, or wave order, also publishes the |r|^2 for the taps)
             if (tid == 0 && live) {
                 const float bpk = sqrtf(best) * out_scale;
