@@ -55,8 +55,12 @@ __device__ __forceinline__ float2 g_cmulc(float2 a, float2 b) {   // a * conj(b)
 // execute in issue order, so the compiler-only fence is enough and no wave waits for another; else a barrier.
 template <bool LOCAL>
 __device__ __forceinline__ void xsync() {
+#ifdef RMX_EXP_NOBAR      // timing experiment only (wrong results): what would the remaining barriers of the register-block kernels cost?
+    wave_lds_order();
+#else
     if constexpr (LOCAL) wave_lds_order();
     else __syncthreads();
+#endif
 }
 // In-place transforms of R = 2^logR points held in LDS; tw[k] = W_R^k, k < R/2.  Up to FOUR radix-2 stages
 // are fused per pass: a radix-16 (8, 4, 2) butterfly in registers -- the blocks of fft_r16.hpp / win8.hpp -- so a

@@ -1626,6 +1626,7 @@ static int generic_init(rmx_ctx* c) {
     if (chunk < 1) chunk = 1;
     if (chunk > c->max_windows) chunk = c->max_windows;
     if (chunk > 4096) chunk = 4096;
+    if (const char* e = getenv("RMX_GEN_CHUNK")) { const long v = atol(e); if (v >= 1 && v < chunk) chunk = v; }   // experiments
     c->g_chunk = (int)chunk;
     return RMX_OK;
 }
