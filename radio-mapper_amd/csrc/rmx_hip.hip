@@ -952,7 +952,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
     {
         const int M2 = (B - 1) * (B - 2) / 2;            // pairs of this phase
         // SIMD pairs {a, a+2} vs {a+1, a+3} (stag 1): measured best of the splits; 0 = nobody, 5 = everybody late
-        const bool late_h2 = stag == 1 ? ((wave >> 1) & 1) : (stag == 5);
+        // (2: odd waves = SIMDs 1, 3; 3: the second wave of every SIMD; 4: one wave of every SIMD, alternating between SIMDs)
+        const bool late_h2 = stag == 1 ? ((wave >> 1) & 1) : stag == 2 ? (wave & 1) : stag == 3 ? (wave >> 2) :
+                             stag == 4 ? ((wave ^ (wave >> 2)) & 1) : (stag == 5);
         auto j_of = [&](int i, int s) -> int { return (i & 1) ? (B - 1 - s) : (i + 1 + s); };
         int ci = 1, cs = 0;                              // pair m     (anchor, position in its run)
         int ni = 1, ns = 1;                              // pair m + 1
