@@ -649,7 +649,7 @@ def test_whole_window_kernel_by_length(xc, N, B, monkeypatch):
     assert np.array_equal(ui, li) and np.all(np.abs(uf - lf) <= TOL) and np.allclose(up, pk, rtol=1e-5)
 
 
-@pytest.mark.parametrize("N,B", [(256, 5), (512, 8), (1024, 6), (2048, 8), (2048, 16), (8192, 3), (8192, 8), (8192, 2)])
+@pytest.mark.parametrize("N,B", [(256, 5), (512, 8), (1024, 6), (2048, 8), (2048, 16), (8192, 3), (8192, 8), (8192, 2), (8192, 4)])
 def test_whole_window_scratch_kernel_by_length(xc, N, B, monkeypatch):
     """Every other shape with 512 <= L <= 16384 -- more than four buoys, or N = 8192 (the capture length of
     iq_stream_client.py:459) -- runs whole windows in one persistent kernel with the spectra in a per-workgroup
@@ -657,7 +657,7 @@ def test_whole_window_scratch_kernel_by_length(xc, N, B, monkeypatch):
     oracle on complex64 and raw uint8 input, more windows than one pass of the grid on the small lengths, a custom
     pair list (reversed, repeated, autocorrelation), and the previous path (RMX_WSCR=0: two-kernel LDS path or
     four-step) on the same input."""
-    W = 700 if N <= 512 else (5 if N >= 8192 else 9)
+    W = 700 if N <= 512 else ((530 if B == 4 else 5) if N >= 8192 else 9)    # (530: every persistent workgroup takes several windows)
     iq, _, raw = rm.synth.make_windows(W, B, N, 2.4e6, seed=800 + B + N % 977, return_u8=True)
     sub = slice(0, min(W, 12))                                   # literal oracle on the first windows, the rest by consistency
     ri, rf, rp = orc.xcorr_batch_literal(iq[sub])
