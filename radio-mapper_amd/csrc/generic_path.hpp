@@ -1070,13 +1070,20 @@ struct WinPlan {
 #ifndef RMX_WS_TWG_FROM
 #define RMX_WS_TWG_FROM 99
 #endif
-    static constexpr bool TW1REG = LOGR >= 12 && LOGR < RMX_WS_TWG_FROM;                  // first pass's twiddles in registers
+#ifndef RMX_WS_TWREG_FROM
+#define RMX_WS_TWREG_FROM 9
+#endif
+    static constexpr bool TW1REG = LOGR >= RMX_WS_TWREG_FROM && LOGR < RMX_WS_TWG_FROM;                  // first pass's twiddles in registers
     static constexpr bool TW1GLOBAL = LOGR >= RMX_WS_TWG_FROM;                            // ... or read from the global table
+#ifndef RMX_WS_TW2REG
+#define RMX_WS_TW2REG 0
+#endif
+    static constexpr bool TW2REG = RMX_WS_TW2REG && NP >= 2 && tpr < 1024;               // the second pass's too
     static constexpr int thr = tpr < kGThreads ? kGThreads : tpr, upw = thr / tpr;         // threads, windows per workgroup
     static constexpr int tab_off(int b) {                                                 // entries in front of pass b's LDS table
         int acc = 0;
         for (int c = LOGR; c > b; c -= 4)
-            if (!(c == LOGR && (TW1REG || TW1GLOBAL))) acc += 15 << (c - 4);
+            if (!(c == LOGR && (TW1REG || TW1GLOBAL)) && !(c == LOGR - 4 && TW2REG)) acc += 15 << (c - 4);
         return acc;
     }
     static constexpr int tab_total = tab_off(ML);
@@ -1093,7 +1100,7 @@ struct WinXf {
     float2* x;
     float2* tab;
     const float2* __restrict__ tw;
-    TwRegs tw1;
+    TwRegs tw1, tw2;
     int tid;
     // tables [k = 1..15][l < q]: W_R^(l k 2^(LOGR - b)), consecutive lanes read consecutive entries; all threads of the
     // workgroup; the caller's barrier follows
@@ -1104,11 +1111,16 @@ struct WinXf {
                 tab[off + e] = tw_full(tw, ((e & (q - 1)) << (LOGR - b)) * ((e >> (b - 4)) + 1), R >> 1);
         };
         if constexpr (!P::TW1REG && !P::TW1GLOBAL) build(std::integral_constant<int, LOGR>{});
-        if constexpr (P::NP >= 2) build(std::integral_constant<int, LOGR - 4>{});
+        if constexpr (P::NP >= 2 && !P::TW2REG) build(std::integral_constant<int, LOGR - 4>{});
         if constexpr (P::NP >= 3) build(std::integral_constant<int, LOGR - 8>{});
         if constexpr (P::TW1REG) {
 #pragma unroll
             for (int k = 1; k < 16; ++k) tw1.w[k - 1] = tw_full(tw, tid * k, R >> 1);
+        }
+        if constexpr (P::TW2REG) {
+            constexpr int b = LOGR - 4, q = 1 << (b - 4);
+#pragma unroll
+            for (int k = 1; k < 16; ++k) tw2.w[k - 1] = tw_full(tw, ((tid & (q - 1)) << (LOGR - b)) * k, R >> 1);
         }
     }
     // forward: v[m] = element tid + m R/16 (m >= 8: the zero-padded half, literal zeros) -> the spectrum in the register
@@ -1132,7 +1144,8 @@ struct WinXf {
         xsync<one_wave>();
         if constexpr (P::NP >= 2) {
             constexpr int bb = LOGR - 4, off = P::tab_off(bb);
-            dif_pass<4, 0, 2>(LOGR, bb, tab + off, tid, tpr, lds, lds);
+            if constexpr (P::TW2REG) dif_pass<4, 0, 3>(LOGR, bb, tw2, tid, tpr, lds, lds);
+            else dif_pass<4, 0, 2>(LOGR, bb, tab + off, tid, tpr, lds, lds);
             xsync<(bb <= 10)>();
         }
         if constexpr (P::NP >= 3) {
@@ -1179,7 +1192,8 @@ struct WinXf {
         if constexpr (P::NP >= 2) {
             constexpr int bb = LOGR - 4, off = P::tab_off(bb);
             xsync<(bb <= 10)>();
-            dit_pass<4, 0, 2>(LOGR, bb, tab + off, tid, tpr, lds, lds);
+            if constexpr (P::TW2REG) dit_pass<4, 0, 3>(LOGR, bb, tw2, tid, tpr, lds, lds);
+            else dit_pass<4, 0, 2>(LOGR, bb, tab + off, tid, tpr, lds, lds);
         }
         xsync<one_wave>();                    // the pass over the whole window reads every wave's blocks
         if constexpr (P::TW1REG) dit_pass<4, 0, 3>(LOGR, LOGR, tw1, tid, tpr, lds, scan);
@@ -1203,7 +1217,7 @@ __global__ __launch_bounds__(WinPlan<LOGR>::thr) void g_win_scr(const void* __re
     float2* tab = reinterpret_cast<float2*>(gsm) + upw * lp(R);
     float* sv = reinterpret_cast<float*>(tab + P::tab_total);
     int* sk = reinterpret_cast<int*>(sv + 16);
-    WinXf<LOGR> xf{x, tab, tw, {}, tid};
+    WinXf<LOGR> xf{x, tab, tw, {}, {}, tid};
     xf.setup();
     __syncthreads();
     float4* scr = scratch + ((long)blockIdx.x * upw + g) * n_buoys * (8L * tpr) + tid;
