@@ -1311,6 +1311,179 @@ __global__ __launch_bounds__(WinPlan<LOGR>::thr) void g_win_scr(const void* __re
     }
 }
 
+// L = 16384 (N = 8192) with 512 threads and TWO butterflies per thread and pass (indices tid and tid + 512): two waves per
+// SIMD with 256 VGPRs each instead of four with 128, which is what the anchor spectrum (64 registers here) and the
+// register twiddles of the pass over the whole window (2 x 30) need -- g_win_scr<14> at 1024 threads has neither and spills.
+// Same passes (16 x 16 x 16 x 4), same LDS image, same scratch idea: [b][u][8][512] float4 per window slot.
+template <bool U8>
+__global__ __launch_bounds__(512, 2) void g_win_scr14(const void* __restrict__ iq, float4* __restrict__ scratch,
+                                                   const float2* __restrict__ tw, int n_buoys, long n_windows,
+                                                   long first_window, float fwd_scale, float out_scale,
+                                                   const GPair* __restrict__ pairs, int n_pairs,
+                                                   int* __restrict__ lag_int, float* __restrict__ lag_frac,
+                                                   float* __restrict__ peak) {
+    extern __shared__ __attribute__((aligned(16))) char gsm[];
+    constexpr int LOGR = 14, R = 1 << LOGR, N = R >> 1, NT = 512, Q = R >> 4;      // Q = 1024 butterflies per radix-16 pass
+    constexpr int off10 = 0, off6 = 15 * 64, tab_total = 15 * 64 + 15 * 4;          // LDS tables of the passes over blocks of 2^10, 2^6
+    const int tid = threadIdx.x;
+    float2* x = reinterpret_cast<float2*>(gsm);
+    float2* tab = x + lp(R);
+    float* sv = reinterpret_cast<float*>(tab + tab_total);
+    int* sk = reinterpret_cast<int*>(sv + 16);
+    for (int e = tid; e < 15 * 64; e += NT) tab[off10 + e] = tw_full(tw, ((e & 63) << 4) * ((e >> 6) + 1), R >> 1);
+    for (int e = tid; e < 15 * 4; e += NT) tab[off6 + e] = tw_full(tw, ((e & 3) << 8) * ((e >> 2) + 1), R >> 1);
+    TwRegs tw1[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int k = 1; k < 16; ++k) tw1[u].w[k - 1] = tw_full(tw, (tid + u * NT) * k, R >> 1);
+    __syncthreads();
+    const LdsIO lds{x};
+    float4* scr = scratch + (long)blockIdx.x * n_buoys * (16L * NT) + tid;          // [b][u][kk][tid]
+    for (long w = blockIdx.x; w < n_windows; w += gridDim.x) {
+        auto load_in = [&](float2 (&d)[2][8], int b) __attribute__((always_inline)) {
+            const long base = (w * n_buoys + b) * (long)N + tid;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    if constexpr (U8) {
+                        const uchar2 b8 = reinterpret_cast<const uchar2*>(iq)[base + u * NT + m * Q];
+                        d[u][m] = make_float2((float)b8.x - 127.5f, (float)b8.y - 127.5f);
+                    } else {
+                        d[u][m] = reinterpret_cast<const float2*>(iq)[base + u * NT + m * Q];
+                    }
+                }
+        };
+        float2 nx[2][8];
+        load_in(nx, 0);
+        for (int b = 0; b < n_buoys; ++b) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {         // first pass: the whole window, elements i + m R/16, i = tid + 512 u
+                float2 v[16];
+#pragma unroll
+                for (int m = 0; m < 8; ++m) { v[m] = nx[u][m]; v[m + 8] = make_float2(0.f, 0.f); }
+                dft16(v);
+                const auto hd = lds.open(tid + u * NT);
+                hd.st(0, v[0]);
+#pragma unroll
+                for (int k = 1; k < 16; ++k) hd.st(brev_m<4>(k) * Q, g_cmul(v[k], tw1[u].w[k - 1]));
+            }
+            if (b + 1 < n_buoys) load_in(nx, b + 1);                                // travels during the rest of this transform
+            __syncthreads();
+            dif_pass<4, 0, 2>(LOGR, 10, tab + off10, tid, NT, lds, lds);
+            xsync<true>();
+            dif_pass<4, 0, 2>(LOGR, 6, tab + off6, tid, NT, lds, lds);
+            xsync<true>();
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {         // the 16 neighbours of butterfly i: four radix-4 butterflies, outputs to the scratch
+                float2 v[16];
+                const auto h = lds.open((tid + u * NT) << 4);
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    float2 t[4];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) t[m] = h.ld(it * 4 + m);
+                    dft_reg<4>(t);
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) v[it * 4 + m] = t[m];
+                }
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk)
+                    scr[(long)((b * 2 + u) * 8 + kk) * NT] = make_float4(v[2 * kk].x * fwd_scale, v[2 * kk].y * fwd_scale,
+                                                                          v[2 * kk + 1].x * fwd_scale, v[2 * kk + 1].y * fwd_scale);
+            }
+            __syncthreads();                      // the next transform's first pass overwrites x
+        }
+        const long obase = (first_window + w) * (long)n_pairs;
+        float4 anc[2][8];                         // the anchor X_i, while consecutive pairs share it
+        int anc_i = -1;
+        for (int q = 0; q < n_pairs; ++q) {
+            const GPair pr = pairs[q];
+            if (pr.i != anc_i) {                  // (workgroup-uniform)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int kk = 0; kk < 8; ++kk) anc[u][kk] = scr[(long)((pr.i * 2 + u) * 8 + kk) * NT];
+                anc_i = pr.i;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {         // X_j conj(X_i) into the neighbour butterflies of the inverse
+                float2 v[16];
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    const float4 a = scr[(long)((pr.j * 2 + u) * 8 + kk) * NT], c = anc[u][kk];
+                    v[2 * kk] = g_cmulc(make_float2(a.x, a.y), make_float2(c.x, c.y));
+                    v[2 * kk + 1] = g_cmulc(make_float2(a.z, a.w), make_float2(c.z, c.w));
+                }
+                const auto h = lds.open((tid + u * NT) << 4);
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    float2 t[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) t[k] = make_float2(v[it * 4 + k].y, v[it * 4 + k].x);
+                    dft_reg<4>(t);
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) h.st(it * 4 + m, make_float2(t[m].y, t[m].x));
+                }
+            }
+            xsync<true>();
+            dit_pass<4, 0, 2>(LOGR, 6, tab + off6, tid, NT, lds, lds);
+            xsync<true>();
+            dit_pass<4, 0, 2>(LOGR, 10, tab + off10, tid, NT, lds, lds);
+            __syncthreads();                      // the pass over the whole window reads every wave's blocks
+            // last pass: outputs n = tid + s 512, s = u + 2 m; |r|^2 into mg[s] and into the buffer (taps)
+            float mg[32];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                float2 v[16];
+                const auto h = lds.open(tid + u * NT);
+                {
+                    const float2 e = h.ld(0);
+                    v[0] = make_float2(e.y, e.x);
+                }
+#pragma unroll
+                for (int k = 1; k < 16; ++k) {
+                    const float2 e = g_cmulc(h.ld(brev_m<4>(k) * Q), tw1[u].w[k - 1]);
+                    v[k] = make_float2(e.y, e.x);
+                }
+                dft16(v);
+#pragma unroll
+                for (int m = 0; m < 16; ++m) {
+                    const float m2 = v[m].x * v[m].x + v[m].y * v[m].y;
+                    mg[u + 2 * m] = m2;
+                    x[lp(tid + u * NT + m * Q)].x = m2;
+                }
+            }
+            // 'full' index n - N - 1 for s >= 16 (lag -N itself: thread 0, s = 16, is not part of the output), n + N - 1 below:
+            // ascending in the order s = 16 .. 31, 0 .. 15
+            if (tid == 0) mg[16] = -2.0f;
+            float best = mg[0];
+#pragma unroll
+            for (int s2 = 1; s2 < 32; ++s2) best = fmaxf(best, mg[s2]);
+            int ssel = 15;
+#pragma unroll
+            for (int s2 = 14; s2 >= 0; --s2) ssel = mg[s2] == best ? s2 : ssel;
+#pragma unroll
+            for (int s2 = 31; s2 >= 16; --s2) ssel = mg[s2] == best ? s2 : ssel;
+            int bk = tid + (ssel & 15) * NT + (ssel >= 16 ? -1 : N - 1);
+            group_argmax<NT>(best, bk, sv, sk, tid, 0);      // (its barrier also publishes the |r|^2 for the taps)
+            if (tid == 0) {
+                const float bpk = sqrtf(best) * out_scale;
+                float frac = 0.0f;
+                if (bk > 0 && bk < 2 * N - 2) {
+                    const float ra = x[lp(circ_index(bk - 1, N))].x, rc = x[lp(circ_index(bk + 1, N))].x;
+                    frac = parabola(sqrtf(ra) * out_scale, bpk, sqrtf(rc) * out_scale);
+                }
+                lag_int[obase + q] = bk - (N - 1);
+                lag_frac[obase + q] = frac;
+                peak[obase + q] = bpk;
+            }
+            __syncthreads();                      // x is rewritten (sv: behind the next inverse's barrier)
+        }
+    }
+}
+
 // ---- column passes of the four-step (no transposes through HBM) ----------------------------------
 // The L-point sequence is the row-major matrix [L1][L2], n = n1*L2 + n2.  A workgroup takes a tile of
 // T = 16 adjacent columns (128-byte row segments: full cache lines; 8 when L1 = 1024) with all L1 rows into LDS

@@ -1607,6 +1607,15 @@ static int generic_init(rmx_ctx* c) {
         c->g_ws_fn[0] = wscr_fn<false>(c->g_logL);
         c->g_ws_fn[1] = wscr_fn<true>(c->g_logL);
         wscr_shape(c->g_logL, &c->g_ws_thr, &c->g_ws_upw, &c->g_ws_lds);
+        // L = 16384: 512 threads x two butterflies (g_win_scr14) unless RMX_WSCR14=0 (1024 threads x one: g_win_scr<14>)
+        bool two = c->g_logL == 14;
+        if (const char* e = getenv("RMX_WSCR14")) two = two && atoi(e) != 0;
+        if (two) {
+            c->g_ws_fn[0] = (const void*)gen::g_win_scr14<false>;
+            c->g_ws_fn[1] = (const void*)gen::g_win_scr14<true>;
+            c->g_ws_thr = 512;
+            c->g_ws_lds = ((size_t)gen::lp(16384) + 15 * 64 + 15 * 4 + 16) * 8;
+        }
         int per_cu = 1;
         for (int u = 0; u < 2; ++u)
             RMX_HIP(c, hipFuncSetAttribute(c->g_ws_fn[u], hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->g_ws_lds));

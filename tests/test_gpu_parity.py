@@ -672,6 +672,11 @@ def test_whole_window_scratch_kernel_by_length(xc, N, B, monkeypatch):
     assert np.array_equal(li, l8) and np.array_equal(lf, f8) and np.array_equal(pk, p8)
     oi, of_, op = orc.xcorr_batch_literal(iq[sub], custom)
     _assert_parity(ci, cf, cp, oi, of_, op)
+    if N == 8192 and B in (3, 8):               # L = 16384 has two builds: 512 threads x two butterflies (default), 1024 x one
+        monkeypatch.setenv("RMX_WSCR14", "0")
+        with xc.XcorrEngine(B, N, W) as eng:
+            ai, af, ap = eng.correlate(iq)
+        assert np.array_equal(ai, li) and np.all(np.abs(af - lf) <= TOL) and np.allclose(ap, pk, rtol=1e-5)
     monkeypatch.setenv("RMX_WSCR", "0")
     monkeypatch.setenv("RMX_WFUSED", "0")
     with xc.XcorrEngine(B, N, W) as eng:
