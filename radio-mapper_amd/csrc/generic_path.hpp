@@ -2,12 +2,17 @@
 //
 // N = 4096 (BASELINE cfg3/cfg4) has the register/LDS-resident radix-16 kernels of rmx_hip.hip.  All
 // other lengths run here: simpler kernels, same definition, same output contract.
-//   L = 2N <= 16384  one workgroup per transform, the whole zero-padded window in LDS (128 KiB at L = 16384,
-//                    i.e. the reference's 8192-sample captures):
+//   512 <= L = 2N <= 16384 (N = 8192: the reference's iq_stream_client captures), batches that fill the chip:
+//                    a workgroup owns a WINDOW and runs all its B + P transforms, spectra never travel as spectra:
+//                      g_win_fused   <= 4 buoys, L <= 4096: the spectra stay in registers
+//                      g_win_scr     any buoy count: spectra in a per-workgroup, cache-resident scratch, persistent grid
+//                      g_win_scr14   L = 16384: the same with 512 threads x two butterflies per pass
+//   L = 2N <= 8192   small batches, the Doppler search, L < 512: one workgroup per transform, the whole zero-padded
+//                    window in LDS:
 //                      g_fwd_small   (window, buoy)  : radix-2 DIF, spectrum left in bit-reversed order
 //                      g_pair_small  (window, pair)  : X_j conj(X_i) -> radix-2 DIT (takes bit-reversed
 //                                                      input, natural output) -> |.|, argmax, parabola
-//   L = 2N  > 16384  four-step transform through HBM in two passes per transform, no transposes: the
+//   L = 2N >= 16384  four-step transform through HBM in two passes per transform, no transposes: the
 //                    sequence is the row-major matrix [L1][L2] (L1 <= 1024 columns-length, L2 = L/L1
 //                    <= 8192), n = n1*L2 + n2:
 //                      forward : g_cols_fwd  tiles of 16 columns x all L1 rows in LDS (up to 128 KiB of

@@ -1811,9 +1811,10 @@ static int generic_pairs(rmx_ctx* c, int w0, int wc, int n_pairs, int* d_lag, fl
 static int generic_batch(rmx_ctx* c, const void* d_iq, int n_windows, int n_pairs, int* d_lag, float* d_frac,
                          float* d_peak, bool u8) {
     // g_win_scr runs a window's B + P transforms one after the other in one workgroup: batches that leave most of the chip
-    // without a workgroup are better off in the per-transform kernels below (8 buoys x 8 windows of 8192: 0.32 vs 0.05 ms;
-    // measured crossovers at 0.5 .. 0.8 workgroups per CU)
-    const bool use_wscr = c->g_wscr && (c->g_wscr_always || ((long)n_windows + c->g_ws_upw - 1) / c->g_ws_upw >= 3L * c->n_cus / 4);
+    // without a workgroup are better off in the per-transform kernels below (8 buoys x 8 windows of 8192: 0.32 vs 0.05 ms).
+    // Measured crossovers (tools/smallw.sh): 0.43 workgroups per CU at L = 16384 (8 buoys; 0.63 with 3), 0.66 .. 0.68 below
+    const long ws_blocks = ((long)n_windows + (c->g_ws_upw > 0 ? c->g_ws_upw : 1) - 1) / (c->g_ws_upw > 0 ? c->g_ws_upw : 1);
+    const bool use_wscr = c->g_wscr && (c->g_wscr_always || ws_blocks >= (c->g_logL == 14 ? 7L : 11L) * c->n_cus / 16);
     int rc = generic_ensure(c, n_pairs, !c->g_wfused && !use_wscr);
     if (rc) return rc;
     if (use_wscr) {
