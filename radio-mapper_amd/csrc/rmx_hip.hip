@@ -1917,7 +1917,8 @@ int rmx_create(rmx_ctx** out, int device_id, int n_buoys, int n_samples, int max
         }
         RMX_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         c->own_stream = true;
-        if (n_samples != kM) return rmx::generic_init(c);
+        // (RMX_GENERIC4096=1: N = 4096 through the generic kernels too -- g_win_scr<13> against k_win, an experiment)
+        if (n_samples != kM || (getenv("RMX_GENERIC4096") && atoi(getenv("RMX_GENERIC4096")) != 0)) return rmx::generic_init(c);
         const char* env = getenv("RMX_CHUNK_WINDOWS");
         int chunk = env ? atoi(env) : 4096;
         if (chunk < 8) chunk = 8;
