@@ -1061,10 +1061,13 @@ __global__ __launch_bounds__(kGThreads, 2) void g_win_fused(const void* __restri
 // threads per window, one radix-16 butterfly per thread and pass) transforms the window's buoys one after the other
 // and parks each spectrum -- in the register order of its last butterfly, 16 bytes per lane, coalesced -- in its own
 // n_buoys x 8 R bytes of global memory, which it overwrites window after window: the scratch of the whole grid stays
-// in the L2 / memory-side cache, HBM sees the input.  Every pair then loads its two spectra back (each thread exactly
-// the values it stored: no visibility protocol), multiplies in registers, and runs the inverse with the peak scan in
-// its last pass.  L = 16384 is one 136 KiB transform per CU with 1024 threads; its first pass's twiddles live in
-// registers (one butterfly per thread: they never change), the others' in small LDS tables.
+// in the L2 / memory-side cache, HBM sees the input.  Every pair then loads X_j back (each thread exactly the values it
+// stored: no visibility protocol; the anchor X_i stays in registers while consecutive pairs share it), multiplies in
+// registers, and runs the inverse with the peak search behind its last pass.  The first pass's twiddles live in registers
+// (one butterfly per thread: they never change), the others' in small LDS tables.  L = 16384 (one 136 KiB transform per
+// CU) runs g_win_scr14 below -- 512 threads x two butterflies -- and this kernel's 1024-thread build only on request.
+// Build knobs (A/B experiments): RMX_WS_TWREG_FROM / RMX_WS_TWG_FROM (first-pass twiddles in
+// registers / from the global table from that log2 L on), RMX_WS_TW2REG (second pass's in registers too).
 // Pass order: radix 16 from the whole window down (DIF) while more than four stages remain, the left-over 1..4
 // stages last, on the thread's 16 neighbouring elements: they end in registers, and the inverse starts there.
 template <int LOGR>
