@@ -626,6 +626,79 @@ __global__ __launch_bounds__(kGThreads) void g_rows(float2* __restrict__ data, c
     }
 }
 
+// Inverse rows with a resident anchor (default pair list: all i < j, i-major; more than four buoys, the Doppler search).
+// g_rows<inverse> above loads X_i's and X_j's row for every pair: 2 P row loads per (window, row index).  Here a
+// workgroup takes the rows `rib` of ONE (window, anchor i) and walks the anchor's pairs (i, j), j = i + 1 .. B - 1: X_i's
+// row stays in registers (R / tpr = 8 complex per thread), so P + B - 1 rows are loaded instead of 2 P, and the row's
+// W_L^(c e) factors (T1, T2: 64 products of two table entries per row) are built once per workgroup instead of once per
+// pair.  Workgroup order: all anchors of a row block one after the other on ONE XCD (consecutive workgroup ids go round
+// robin over the 8 XCDs), so the X_j rows that the anchors i < j share are L2 hits.
+// grid: x = (n_rows / rpw) * (n_buoys - 1), y = windows of the chunk.
+template <int LOGR>
+__global__ __launch_bounds__(kGThreads) void g_rows_anchor(float2* __restrict__ data, const float2* __restrict__ tw,
+                                                           int n_rows, int row_bits, long Ltot, int lo_bits,
+                                                           const float2* __restrict__ thi, const float2* __restrict__ tlo,
+                                                           float scale, const float2* __restrict__ spec,
+                                                           const float2* __restrict__ spec_j, int n_pairs, int n_buoys) {
+    extern __shared__ __attribute__((aligned(16))) char gsm[];
+    constexpr int logR = LOGR, R = 1 << LOGR, tpr = rows_tpr(R), rpw = kGThreads / tpr, EPT = R / tpr;   // elements per thread
+    const int g = threadIdx.x / tpr, tid = threadIdx.x % tpr;
+    float2* x = reinterpret_cast<float2*>(gsm) + (long)g * lp(R);
+    constexpr int a = logR >> 1, n1 = 1 << a, n2 = R >> a;
+    float2* t1 = reinterpret_cast<float2*>(gsm) + (long)rpw * lp(R) + (long)g * (n1 + n2);
+    float2* t2 = t1 + n1;
+    float2* twl = reinterpret_cast<float2*>(gsm) + (long)rpw * lp(R) + (long)rpw * (n1 + n2);
+    for (int k = threadIdx.x; k < (R >> 1); k += kGThreads) twl[k] = tw[k];
+    float2* tw16 = twl + (R >> 1);
+    constexpr bool own16 = logR > 8 && logR < 12;
+    if constexpr (own16) build_tw16(tw16, tw, logR, threadIdx.x, kGThreads);
+    const int nrb = n_rows / rpw, na = n_buoys - 1, bid = blockIdx.x;
+    int rb, i;
+    if ((nrb & 7) == 0) {
+        const int s = bid >> 3;
+        rb = (s / na) * 8 + (bid & 7);
+        i = s % na;
+    } else {
+        rb = bid / na;
+        i = bid % na;
+    }
+    const int rib = rb * rpw + g;
+    const long wl = blockIdx.y;
+    {   // W_L^(c*e) for this row's multiplier c and every exponent e < R = T1[e & (2^a - 1)] * T2[e >> a]
+        const long c = (long)brev(rib, row_bits);
+        for (int e = tid; e < n1 + n2; e += tpr) {
+            const long ee = e < n1 ? (long)e : ((long)(e - n1) << a);
+            t1[e] = big_tw((c * ee) & (Ltot - 1), lo_bits, thi, tlo);
+        }
+    }
+    float2 anc[EPT];
+    {
+        const float2* xi = spec + (((long)wl * n_buoys + i) * n_rows + rib) * R;
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) anc[k] = xi[tid + k * tpr];
+    }
+    const LdsIO lds{x};
+    const int q0 = i * n_buoys - (i * (i + 1)) / 2 - (i + 1);        // pair (i, j) is number q0 + j of the i-major list
+    for (int j = i + 1; j < n_buoys; ++j) {
+        const float2* xj = spec_j + (((long)wl * n_buoys + j) * n_rows + rib) * R;
+        float2 v[EPT];
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) v[k] = xj[tid + k * tpr];
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) x[lp(tid + k * tpr)] = g_cmulc(v[k], anc[k]);       // X_j conj(X_i)
+        __syncthreads();                                  // (the first trip: the tables too)
+        fft_dit_inv<0>(x, logR, twl, tid, tpr, lds, lds, own16 ? tw16 : nullptr);
+        __syncthreads();
+        float2* row = data + (((long)wl * n_pairs + (q0 + j)) * n_rows + rib) * R;
+        for (int n = tid; n < R; n += tpr) {
+            const float2 w = g_cmul(t1[n & (n1 - 1)], t2[n >> a]);
+            const float2 r = g_cmulc(x[lp(n)], w);
+            row[n] = make_float2(r.x * scale, r.y * scale);
+        }
+        __syncthreads();                                  // x is rewritten
+    }
+}
+
 // ---- both row passes in one kernel (few buoys) ---------------------------------------------------------------
 // The inverse row pass of pair (i, j) needs row `rib` of X_i and X_j only, and that row of a spectrum is the forward
 // row transform of row `rib` of the column pass's output.  With few buoys a workgroup therefore does everything for

@@ -1192,6 +1192,7 @@ struct rmx_ctx {
     const void* g_cols_inv_fn = nullptr;
     const void* g_cols_fwd_fn[2] = {nullptr, nullptr};   // [u8]
     const void* g_rows_inv_fn = nullptr;
+    const void* g_rows_anchor_fn = nullptr;   // inverse rows with a resident anchor (default pair list), or null
     const void* g_rows_fwd_fn = nullptr;   // g_rows<inverse> compiled for this row length (or the run-time one)
     float2 *g_tw = nullptr, *g_tw1 = nullptr, *g_tw2 = nullptr, *g_thi = nullptr, *g_tlo = nullptr;
     float2 *g_spec = nullptr, *g_spec_r = nullptr, *g_prod = nullptr;   // spectra, de-rotated spectra (CAF), products
@@ -1447,6 +1448,18 @@ static const void* rows_inv_fn(int logR, int tpr) {       // the inverse row ker
         default: return (const void*)g_rows<false, true, true>;
     }
 }
+static const void* rows_anchor_fn(int logR, int tpr) {
+    using namespace gen;
+    if (tpr != rows_tpr(1 << logR)) return nullptr;
+    switch (logR) {
+        case 9: return (const void*)g_rows_anchor<9>;
+        case 10: return (const void*)g_rows_anchor<10>;
+        case 11: return (const void*)g_rows_anchor<11>;
+        case 12: return (const void*)g_rows_anchor<12>;
+        case 13: return (const void*)g_rows_anchor<13>;
+        default: return nullptr;
+    }
+}
 static const void* fused_fn(int nb, int logR, bool def) {   // g_rows_fused<n_buoys, log2 row length, default plan>
 #define RMX_FF(NB, D) (logR == 9 ? (const void*)gen::g_rows_fused<NB, 9, D> : logR == 10 ? (const void*)gen::g_rows_fused<NB, 10, D> : \
                        logR == 11 ? (const void*)gen::g_rows_fused<NB, 11, D> : (const void*)gen::g_rows_fused<NB, 12, D>)
@@ -1574,6 +1587,10 @@ static int generic_init(rmx_ctx* c) {
         c->g_rows_fwd_fn = rows_fwd_fn(c->g_logL2, gen_rows_tpr(1 << c->g_logL2));
         RMX_HIP(c, hipFuncSetAttribute(c->g_rows_fwd_fn, hipFuncAttributeMaxDynamicSharedMemorySize, rows_lds));
         RMX_HIP(c, hipFuncSetAttribute(c->g_rows_inv_fn, hipFuncAttributeMaxDynamicSharedMemorySize, rows_lds));
+        c->g_rows_anchor_fn = rows_anchor_fn(c->g_logL2, gen_rows_tpr(1 << c->g_logL2));
+        if (const char* e = getenv("RMX_ROWS_ANCHOR")) { if (atoi(e) == 0) c->g_rows_anchor_fn = nullptr; }
+        if (c->g_rows_anchor_fn)
+            RMX_HIP(c, hipFuncSetAttribute(c->g_rows_anchor_fn, hipFuncAttributeMaxDynamicSharedMemorySize, rows_lds));
         // both row passes in one kernel when the buoys' spectra rows fit the register file (generic_path.hpp)
         c->g_fused = c->n_buoys <= 4 && c->g_logL2 >= 9 && c->g_logL2 <= 12;
         if (const char* e = getenv("RMX_FUSED")) {      // 0: never, 2: also for batches too small to fill the chip (tests)
@@ -1782,6 +1799,16 @@ static int generic_pairs(rmx_ctx* c, int w0, int wc, int n_pairs, int* d_lag, fl
         void* args[] = {&colsp, &prodp, &twp, &a_L1, &a_l1, &a_L, &a_lo, &thip, &tlop, &a_scale, &a_units, &pp, &a_np};
         RMX_HIP(c, hipLaunchKernel(def_plan ? c->g_fused_def_fn : c->g_fused_fn, grid, dim3(kGThreads), args,
                                    gen_fused_lds(L2, def_plan && gen::fused_tw_regs(B, l2, true)), st));
+    } else if (c->g_rows_anchor_fn && c->plan_all_pairs && n_pairs == B * (B - 1) / 2 && B >= 8) {
+        // default pair list: the anchor's row stays in registers over its run of pairs (from 8 buoys on: with 5 the runs are
+        // too short for the per-workgroup set-up, 0.655 -> 0.692 ms at N = 16384; with 8 1.54 -> 1.41 ms, cfg5 250 -> 223 ms)
+        float2* a_data = c->g_prod;
+        const float2 *a_tw = c->g_tw2, *a_thi = c->g_thi, *a_tlo = c->g_tlo, *a_spec = c->g_spec, *a_specj = spec_j;
+        int a_L1 = L1, a_l1 = l1, a_lo = c->g_lo_bits, a_np = n_pairs, a_B = B;
+        long a_L = L;
+        float a_scale = 1.0f;
+        void* args[] = {&a_data, &a_tw, &a_L1, &a_l1, &a_L, &a_lo, &a_thi, &a_tlo, &a_scale, &a_spec, &a_specj, &a_np, &a_B};
+        RMX_HIP(c, hipLaunchKernel(c->g_rows_anchor_fn, dim3((unsigned)((L1 / rpw) * (B - 1)), (unsigned)wc), dim3(kGThreads), args, rlds, st));
     } else
     {
         float2* a_data = c->g_prod;
