@@ -671,29 +671,41 @@ __global__ __launch_bounds__(kGThreads) void g_rows_anchor(float2* __restrict__ 
             t1[e] = big_tw((c * ee) & (Ltot - 1), lo_bits, thi, tlo);
         }
     }
-    float2 anc[EPT];
+    // rows travel as float4 (two complex per lane and load): thread tid owns elements 2 tid + {0, 1} + 2 tpr k
+    static_assert(EPT % 2 == 0, "two complex per load");
+    float4 anc[EPT / 2];
     {
-        const float2* xi = spec + (((long)wl * n_buoys + i) * n_rows + rib) * R;
+        const float4* xi = reinterpret_cast<const float4*>(spec + (((long)wl * n_buoys + i) * n_rows + rib) * R);
 #pragma unroll
-        for (int k = 0; k < EPT; ++k) anc[k] = xi[tid + k * tpr];
+        for (int k = 0; k < EPT / 2; ++k) anc[k] = xi[tid + k * tpr];
     }
     const LdsIO lds{x};
     const int q0 = i * n_buoys - (i * (i + 1)) / 2 - (i + 1);        // pair (i, j) is number q0 + j of the i-major list
+    auto load_row = [&](float4 (&d)[EPT / 2], int j) __attribute__((always_inline)) {
+        const float4* xj = reinterpret_cast<const float4*>(spec_j + (((long)wl * n_buoys + j) * n_rows + rib) * R);
+#pragma unroll
+        for (int k = 0; k < EPT / 2; ++k) d[k] = xj[tid + k * tpr];
+    };
+    float4 nx[EPT / 2];
+    load_row(nx, i + 1);
     for (int j = i + 1; j < n_buoys; ++j) {
-        const float2* xj = spec_j + (((long)wl * n_buoys + j) * n_rows + rib) * R;
-        float2 v[EPT];
 #pragma unroll
-        for (int k = 0; k < EPT; ++k) v[k] = xj[tid + k * tpr];
-#pragma unroll
-        for (int k = 0; k < EPT; ++k) x[lp(tid + k * tpr)] = g_cmulc(v[k], anc[k]);       // X_j conj(X_i)
+        for (int k = 0; k < EPT / 2; ++k) {               // X_j conj(X_i)
+            const int n = 2 * (tid + k * tpr);
+            x[lp(n)] = g_cmulc(make_float2(nx[k].x, nx[k].y), make_float2(anc[k].x, anc[k].y));
+            x[lp(n + 1)] = g_cmulc(make_float2(nx[k].z, nx[k].w), make_float2(anc[k].z, anc[k].w));
+        }
+        if (j + 1 < n_buoys) load_row(nx, j + 1);         // the next pair's row travels during this inverse
         __syncthreads();                                  // (the first trip: the tables too)
         fft_dit_inv<0>(x, logR, twl, tid, tpr, lds, lds, own16 ? tw16 : nullptr);
         __syncthreads();
-        float2* row = data + (((long)wl * n_pairs + (q0 + j)) * n_rows + rib) * R;
-        for (int n = tid; n < R; n += tpr) {
-            const float2 w = g_cmul(t1[n & (n1 - 1)], t2[n >> a]);
-            const float2 r = g_cmulc(x[lp(n)], w);
-            row[n] = make_float2(r.x * scale, r.y * scale);
+        float4* row = reinterpret_cast<float4*>(data + (((long)wl * n_pairs + (q0 + j)) * n_rows + rib) * R);
+#pragma unroll
+        for (int k = 0; k < EPT / 2; ++k) {               // two neighbouring elements per 16-byte store
+            const int n = 2 * (tid + k * tpr);
+            const float2 w0 = g_cmul(t1[n & (n1 - 1)], t2[n >> a]), w1 = g_cmul(t1[(n + 1) & (n1 - 1)], t2[(n + 1) >> a]);
+            const float2 r0 = g_cmulc(x[lp(n)], w0), r1 = g_cmulc(x[lp(n + 1)], w1);
+            row[tid + k * tpr] = make_float4(r0.x * scale, r0.y * scale, r1.x * scale, r1.y * scale);
         }
         __syncthreads();                                  // x is rewritten
     }
