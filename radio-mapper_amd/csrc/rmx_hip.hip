@@ -1193,6 +1193,7 @@ struct rmx_ctx {
     const void* g_cols_fwd_fn[2] = {nullptr, nullptr};   // [u8]
     const void* g_rows_inv_fn = nullptr;
     const void* g_rows_anchor_fn = nullptr;   // inverse rows with a resident anchor (default pair list), or null
+    int g_rows_anchor_min_b = 6;              // ... from this many buoys on (RMX_ROWS_ANCHOR=n sets it, 0 = never)
     const void* g_rows_fwd_fn = nullptr;   // g_rows<inverse> compiled for this row length (or the run-time one)
     float2 *g_tw = nullptr, *g_tw1 = nullptr, *g_tw2 = nullptr, *g_thi = nullptr, *g_tlo = nullptr;
     float2 *g_spec = nullptr, *g_spec_r = nullptr, *g_prod = nullptr;   // spectra, de-rotated spectra (CAF), products
@@ -1588,7 +1589,7 @@ static int generic_init(rmx_ctx* c) {
         RMX_HIP(c, hipFuncSetAttribute(c->g_rows_fwd_fn, hipFuncAttributeMaxDynamicSharedMemorySize, rows_lds));
         RMX_HIP(c, hipFuncSetAttribute(c->g_rows_inv_fn, hipFuncAttributeMaxDynamicSharedMemorySize, rows_lds));
         c->g_rows_anchor_fn = rows_anchor_fn(c->g_logL2, gen_rows_tpr(1 << c->g_logL2));
-        if (const char* e = getenv("RMX_ROWS_ANCHOR")) { if (atoi(e) == 0) c->g_rows_anchor_fn = nullptr; }
+        if (const char* e = getenv("RMX_ROWS_ANCHOR")) { const int v = atoi(e); if (v == 0) c->g_rows_anchor_fn = nullptr; else if (v >= 2) c->g_rows_anchor_min_b = v; }
         if (c->g_rows_anchor_fn)
             RMX_HIP(c, hipFuncSetAttribute(c->g_rows_anchor_fn, hipFuncAttributeMaxDynamicSharedMemorySize, rows_lds));
         // both row passes in one kernel when the buoys' spectra rows fit the register file (generic_path.hpp)
@@ -1799,9 +1800,10 @@ static int generic_pairs(rmx_ctx* c, int w0, int wc, int n_pairs, int* d_lag, fl
         void* args[] = {&colsp, &prodp, &twp, &a_L1, &a_l1, &a_L, &a_lo, &thip, &tlop, &a_scale, &a_units, &pp, &a_np};
         RMX_HIP(c, hipLaunchKernel(def_plan ? c->g_fused_def_fn : c->g_fused_fn, grid, dim3(kGThreads), args,
                                    gen_fused_lds(L2, def_plan && gen::fused_tw_regs(B, l2, true)), st));
-    } else if (c->g_rows_anchor_fn && c->plan_all_pairs && n_pairs == B * (B - 1) / 2 && B >= 8) {
-        // default pair list: the anchor's row stays in registers over its run of pairs (from 8 buoys on: with 5 the runs are
-        // too short for the per-workgroup set-up, 0.655 -> 0.692 ms at N = 16384; with 8 1.54 -> 1.41 ms, cfg5 250 -> 223 ms)
+    } else if (c->g_rows_anchor_fn && c->plan_all_pairs && n_pairs == B * (B - 1) / 2 && B >= c->g_rows_anchor_min_b) {
+        // default pair list: the anchor's row stays in registers over its run of pairs (from 6 buoys on: with 5 the runs are
+        // too short for the per-workgroup set-up, 0.649 -> 0.692 ms at N = 16384; with 6 / 7 / 8 buoys 0.89 -> 0.84, 1.16 -> 1.10,
+        // 1.54 -> 1.39 ms, cfg5 250 -> 203 ms)
         float2* a_data = c->g_prod;
         const float2 *a_tw = c->g_tw2, *a_thi = c->g_thi, *a_tlo = c->g_tlo, *a_spec = c->g_spec, *a_specj = spec_j;
         int a_L1 = L1, a_l1 = l1, a_lo = c->g_lo_bits, a_np = n_pairs, a_B = B;
