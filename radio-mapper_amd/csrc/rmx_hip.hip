@@ -25,6 +25,7 @@
 
 #include "../../include/rmx.h"
 #include "fft_r16.hpp"
+#include "kwin.hpp"
 #include "win8.hpp"
 #include "winpk.hpp"
 #include "generic_path.hpp"
@@ -32,45 +33,11 @@
 
 namespace rmx {
 
-using u32x4 = unsigned int __attribute__((ext_vector_type(4)));
-using u32x2 = unsigned int __attribute__((ext_vector_type(2)));
-using f32x4 = float __attribute__((ext_vector_type(4)));
-using f32x2 = float __attribute__((ext_vector_type(2)));
-// NOTE: __builtin_bit_cast(float, vec.y) on a vector ELEMENT is mis-lowered by this hipcc (every
-// element reads lane 0 of the vector); always bit_cast the whole vector, then take elements.
 
 struct PairItem {
     int i, j, out, run;   // run: items left in this anchor run (same i), this one included
 };
 
-// LDS carve (bytes) of both kernels: exchange image, TW2 table, reduction words
-constexpr int kLdsXchg = kXchgF2 * 8;                  // 69632
-constexpr int kLdsTw2 = 16 * kTw2RowF2 * 8;            // 2304
-constexpr int kLdsRed = 64;
-constexpr int kLdsBytes = kLdsXchg + kLdsTw2 + kLdsRed;
-
-__device__ __forceinline__ void load_tw2_to_lds(float2* tw2_lds, const float2* __restrict__ tw2_g, int t) {
-    // tw2_g: [16][16] complex; LDS rows padded to kTw2RowF2
-    if (t < 256) tw2_lds[(t >> 4) * kTw2RowF2 + (t & 15)] = tw2_g[t];
-}
-
-// same table in layer-1 group order for dft16_tw_row: stored[4*q0 + m - 1] = tw2[a][q0 + 4*m]; the
-// unused tw2[a][0] = 1 goes to the pad slot 15
-__device__ __forceinline__ void load_tw2_to_lds_grouped(float2* tw2_lds, const float2* __restrict__ tw2_g, int t) {
-    if (t < 256) {
-        const int a = t >> 4, q = t & 15;
-        tw2_lds[a * kTw2RowF2 + (q == 0 ? 15 : 4 * (q & 3) + (q >> 2) - 1)] = tw2_g[t];
-    }
-}
-
-__device__ __forceinline__ void load_tw1(float2 (&tw1)[16], const float4* __restrict__ tw1_g, int t) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float4 w = tw1_g[j * kThreads + t];
-        tw1[2 * j] = make_float2(w.x, w.y);
-        tw1[2 * j + 1] = make_float2(w.z, w.w);
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
 // Forward spectra.  grid = n_items workgroups of 512; item = wl * B + b inside the chunk.
@@ -484,517 +451,6 @@ __global__ __launch_bounds__(kThreads, 2) void k_pair_res(
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Fused window kernel: one workgroup (512 threads, <= 256 VGPRs, one per CU) per capture window.
-//   phase 1  forward spectra of all B buoys -> this window's scratch (thread-private layout: every
-//            thread later re-reads exactly the float4s it stored, so no visibility protocol is needed)
-//   phase 2  anchor runs over the pair list: X_i stays in registers for its run, X_j streams one pair
-//            ahead; conj-multiply merged into the first radix-16 pass; ONE workgroup barrier per pair.
-// LDS: two exchange images (alternating by transform/pair, which is what makes one barrier enough:
-// a wave only writes its own half-wave regions of the image the others are not reading), the TW2
-// table, and two small double-buffered records per wave for the argmax: the wave's winner with its
-// in-wave neighbour taps, and a "halo" of the |r|^2 of its lanes 0,1,62,63 for neighbours that sit
-// in another wave.  The pair's winner is resolved by one lane after the NEXT pair's barrier.
-constexpr int kLdsWinImg = kLdsXchg;                                 // 69632 each, two of them
-constexpr int kLdsWinTw2 = 2 * kLdsWinImg;
-constexpr int kResSlots = 8;   // record ring; winners are resolved in batches of kResBatch pairs
-constexpr int kResBatch = 7;   // < kResSlots: the pair after a batch writes a slot the resolver is not reading
-constexpr int kLdsWinHalo = kLdsWinTw2 + kLdsTw2;                           // [slots][8][4][16] float
-constexpr int kLdsWinRed = kLdsWinHalo + kResSlots * 8 * 4 * 16 * 4;        // [slots][8] float4
-constexpr int kLdsWinOidx = kLdsWinRed + kResSlots * 8 * 16;                // [slots] int: output slot of the pair
-constexpr int kLdsWinBytes = kLdsWinOidx + kResSlots * 4;
-static_assert(kLdsWinBytes <= 160 * 1024, "k_win LDS");
-
-__device__ __forceinline__ void k_to_owner(int kk, int& tt, int& q) {
-    const int par = (kk >= kM - 1) ? 0 : 1;
-    const int n = par ? (kk + 1) : (kk - (kM - 1));
-    tt = 2 * (n & 255) + par;
-    q = n >> 8;
-}
-
-// Executed by ONE whole wave after a barrier that published the records of `cnt` <= 7 pairs (ring
-// slots first, first+1, ...): lane = 8*g + r looks at wave r's record of the g-th pair, two DPP
-// reductions over each group of 8 lanes pick (max |r|^2, lowest 'full' index), the neighbour taps
-// come from the winner's own record or from the halo rows, and the winning lane of every group
-// stores the pair's 12 bytes.  One resolve per 7 pairs instead of one per pair: the resolving wave
-// is late to its next barrier by the length of this routine, and the other seven wait for it.
-__device__ __forceinline__ void resolve_batch(int lane, const float4* red, const float* halo, const int* oidx,
-                                              int first, int cnt, long obase, float out_scale,
-                                              int* __restrict__ lag_int, float* __restrict__ lag_frac,
-                                              float* __restrict__ peak) {
-    const int g = lane >> 3, r = lane & 7;
-    const bool act = g < cnt;
-    const int slot = (first + g) & (kResSlots - 1);
-    // record = {max |r|^2, its lowest 'full' index (int bits), tap k*-1, tap k*+1}; scalar LDS reads
-    const float* rf = reinterpret_cast<const float*>(red) + 4 * (slot * 8 + r);
-    const int* ri = reinterpret_cast<const int*>(rf);
-    const float ex = act ? rf[0] : -3.0f;
-    const int k = act ? ri[1] : 0x7fffffff;
-    const float tm = rf[2], tp = rf[3];
-    const int out = oidx[slot];
-    float gmax = ex;                                     // max over the 8 lanes of the group
-    gmax = fmaxf(gmax, __builtin_bit_cast(float, dpp_i<0xB1>(__builtin_bit_cast(int, gmax))));
-    gmax = fmaxf(gmax, __builtin_bit_cast(float, dpp_i<0x4E>(__builtin_bit_cast(int, gmax))));
-    gmax = fmaxf(gmax, __builtin_bit_cast(float, dpp_i<0x141>(__builtin_bit_cast(int, gmax))));
-    int kstar = (ex == gmax) ? k : 0x7fffffff;
-    kstar = min(kstar, dpp_i<0xB1>(kstar));
-    kstar = min(kstar, dpp_i<0x4E>(kstar));
-    kstar = min(kstar, dpp_i<0x141>(kstar));
-    const bool win = act && ex == gmax && k == kstar;     // exactly one lane per active group
-    // halo rows (always read, clamped): only lanes 0,1,62,63 of a wave can own a cross-wave neighbour
-    auto halo_tap = [&](int kk) -> float {
-        kk = kk < 0 ? 0 : (kk > 2 * kM - 2 ? 2 * kM - 2 : kk);
-        int tt, q;
-        k_to_owner(kk, tt, q);
-        const int ln = tt & 63;
-        const int row = ln < 2 ? ln : (ln >= 62 ? ln - 60 : 0);
-        return halo[(((slot * 8 + (tt >> 6)) * 4) + row) * 16 + q];
-    };
-    const int kc = win ? k : (kM - 1);
-    const float hm = halo_tap(kc - 1), hp = halo_tap(kc + 1);
-    const float b = sqrtf(fmaxf(ex, 0.0f)) * out_scale;
-    const float a = sqrtf(tm >= 0.0f ? tm : hm) * out_scale;
-    const float c = sqrtf(tp >= 0.0f ? tp : hp) * out_scale;
-    const double den = (double)a - 2.0 * (double)b + (double)c;
-    float frac = 0.0f;
-    if (kc > 0 && kc < 2 * kM - 2 && den != 0.0) frac = (float)(0.5 * ((double)a - (double)c) / den);
-    if (win) {
-        lag_int[obase + out] = kc - (kM - 1);
-        lag_frac[obase + out] = frac;
-        peak[obase + out] = b;
-    }
-}
-
-// Schedule of one window (all pairs i<j of B buoys; the anchor spectrum X_i is resident in registers,
-// X_j streams one pair ahead):
-//   anchor 0      X_0 is transformed straight into the anchor registers (never stored); every further
-//                 X_e is transformed once, stored once, and used at once, from registers, for (0,e);
-//   anchor i>=1   one anchor load, then the X_j stream, walking j down for odd i and up for even i so
-//                 that each anchor starts on the spectra the previous one touched last.
-// HBM/L2 traffic per window at B = 8: 8 inputs (256 KiB) + 7 spectrum stores (448 KiB) + 27
-// spectrum loads of 64 KiB, of which ~8 are L2-hot, instead of 8 stores + 35 loads.
-template <bool U8>
-__global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq_v, float4* __restrict__ spec,
-                                                     const float4* __restrict__ tw1_g,
-                                                     const float2* __restrict__ tw2_g, int n_buoys,
-                                                     long first_window, float out_scale,
-                                                     int* __restrict__ lag_int, float* __restrict__ lag_frac,
-                                                     float* __restrict__ peak, int n_win, int dbg_rt, int stag) {
-#ifdef RMX_ABLATE
-    const int dbg = dbg_rt;   // timing-only ablation build (wrong results): tools/ablate.sh, tools/ablate_run.py
-#else
-    constexpr int dbg = 0;
-    (void)dbg_rt;
-#endif
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float2* img0 = reinterpret_cast<float2*>(smem);
-    float2* img1 = reinterpret_cast<float2*>(smem + kLdsWinImg);
-    float2* tw2_lds = reinterpret_cast<float2*>(smem + kLdsWinTw2);
-    float* halo = reinterpret_cast<float*>(smem + kLdsWinHalo);
-    float4* red = reinterpret_cast<float4*>(smem + kLdsWinRed);
-    int* oidx = reinterpret_cast<int*>(smem + kLdsWinOidx);
-
-    const int t = threadIdx.x;
-    const int p = t & 1, u = t >> 1;
-    const int lane = t & 63, wave = t >> 6;
-    const int B = n_buoys;
-    const int n_pairs = B * (B - 1) / 2;
-
-    load_tw2_to_lds_grouped(tw2_lds, tw2_g, t);
-    float2 tw1[16];
-    load_tw1(tw1, tw1_g, t);
-    const float4* tw2row = reinterpret_cast<const float4*>(tw2_lds + (u & 15) * kTw2RowF2);
-    const float sgn = p ? -1.0f : 1.0f;
-    const int kbase = p ? (u - 1) : (u + kM - 1);
-    const int hl = lane < 2 ? lane : lane - 60;            // halo row of lanes 0,1,62,63
-    const bool is_halo = lane < 2 || lane >= 62;
-    __syncthreads();
-#ifndef RMX_TW2_LDS
-    // this thread's TW2 row W_256^(n0*k1), k1 = 0..15, kept in registers for the whole launch (30 of the 60 VGPRs
-    // this kernel left unused at 2 waves per SIMD) instead of eight ds_read_b128 per transform: LDS array time is
-    // not hidden behind the butterflies in this kernel, so the 11 % of it that these reads
-    // were came off the launch time one for one (1.778 -> 1.728 ms); -DRMX_TW2_LDS restores the LDS reads
-    C16 tw2r;
-    {
-        const float2* rowf2 = reinterpret_cast<const float2*>(tw2row);
-        tw2r.set(0, 1.0f, 0.0f);
-#pragma unroll
-        for (int q = 1; q < 16; ++q) {
-            const float2 w = rowf2[4 * (q & 3) + (q >> 2) - 1];
-            tw2r.set(q, w.x, w.y);
-        }
-    }
-#endif
-
-    // persistent workgroup: the tables above are loaded once, then windows blockIdx.x, +gridDim.x, ...
-    for (int wl = blockIdx.x; wl < n_win; wl += gridDim.x) {
-    C16 sa, sb;   // anchor spectrum X_i and the streamed X_j (scalar arrays: see C16)
-    // spectrum scratch is per WORKGROUP, not per window: the persistent workgroup reuses the same
-    // B x 64 KiB for every window it processes (256 x 448 KiB = 115 MB live for the whole launch,
-    // resident in the 256 MB Infinity Cache, rewritten before most of it is ever evicted to HBM)
-    const long wbase = (long)blockIdx.x * B;
-    const long obase = (first_window + wl) * (long)n_pairs;
-    int seq = 0;         // transform counter: selects the exchange image
-    int npair = 0;       // pair counter: selects the record slot (ring of kResSlots)
-    int npend = 0;       // pairs whose records await a resolve
-
-
-    auto barrier_hook = [&](bool flush) __attribute__((always_inline)) {
-        if (!(dbg & 1)) __syncthreads();
-        if (npend == kResBatch || (flush && npend > 0)) {
-            if (!(dbg & 2) && wave == (seq & 7))
-                resolve_batch(lane, red, halo, oidx, (npair - npend) & (kResSlots - 1), npend, obase, out_scale, lag_int,
-                              lag_frac, peak);
-            npend = 0;
-        }
-    };
-    // odd lanes: v[q] *= W32^q, the per-slot part of the odd sub-transform's W_L^n (in place)
-    auto mul_w32_odd = [&](float2 (&v)[16]) __attribute__((always_inline)) {
-        if (p) {
-            {   // q = 1..3 one by one, then three groups of four in one asm statement each
-#pragma unroll
-                for (int q = 1; q < 4; ++q) {
-                    const float2 w = w32(q);
-                    float x = v[q].x, y = v[q].y;   // scalars by value: keeps the array out of scratch
-                    cmul_inplace(x, y, w.x, w.y);
-                    v[q].x = x;
-                    v[q].y = y;
-                }
-            }
-#pragma unroll
-            for (int q = 4; q < 16; q += 4) {
-                float x0 = v[q].x, y0 = v[q].y, x1 = v[q + 1].x, y1 = v[q + 1].y;
-                float x2 = v[q + 2].x, y2 = v[q + 2].y, x3 = v[q + 3].x, y3 = v[q + 3].y;
-                cmul4_inplace(x0, y0, x1, y1, x2, y2, x3, y3, w32(q), w32(q + 1), w32(q + 2), w32(q + 3));
-                v[q].x = x0; v[q].y = y0; v[q + 1].x = x1; v[q + 1].y = y1;
-                v[q + 2].x = x2; v[q + 2].y = y2; v[q + 3].x = x3; v[q + 3].y = y3;
-            }
-        }
-    };
-    // All global traffic of the loop goes through buffer descriptors held in SGPRs: address = SRD
-    // base + one shared 32-bit VGPR offset + an SGPR/immediate offset.  (With flat 64-bit addressing
-    // hipcc keeps ~100 VGPRs of loop-invariant addresses alive and spills the twiddles instead.)
-    const int samp_bytes = U8 ? 2 : 8;
-    const __amdgpu_buffer_rsrc_t xs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(reinterpret_cast<const char*>(iq_v)) + (first_window + wl) * (long)B * kM * samp_bytes, 0,
-        B * kM * samp_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ss = __builtin_amdgcn_make_buffer_rsrc(
-        reinterpret_cast<char*>(spec) + wbase * (long)(8 * kThreads * 16), 0, B * (8 * kThreads * 16), 0x00020000);
-    const int xoff = u * samp_bytes, soff = t * 16;
-    // raw window samples of buoy b into d (uint8 pairs stay packed in d[q].x until cvt_x)
-    auto load_x = [&](C16& d, int b) __attribute__((always_inline)) {
-        if constexpr (U8) {
-#pragma unroll
-            for (int q = 0; q < 16; ++q)
-                d.re[q] = __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b16(xs, xoff, (b * kM + q * 256) * 2, 0));
-        } else {
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(xs, xoff, (b * kM + q * 256) * 8, 0);
-                d.set(q, __uint_as_float(r.x), __uint_as_float(r.y));   // (by value: see NOTE)
-            }
-        }
-    };
-    // quarter G of the same loads (slots 4G..4G+3): issued between the groups of a butterfly layer
-    auto load_x_part_from = [&](const __amdgpu_buffer_rsrc_t& rs, C16& d, int b, auto part) __attribute__((always_inline)) {
-        constexpr int G = decltype(part)::value;
-        if (dbg & 64) return;   // ablation: no window-sample requests
-        if constexpr (U8) {
-#pragma unroll
-            for (int q = 4 * G; q < 4 * G + 4; ++q)
-                d.re[q] = __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs, xoff, (b * kM + q * 256) * 2, 0));
-        } else {
-#pragma unroll
-            for (int q = 4 * G; q < 4 * G + 4; ++q) {
-                const u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(rs, xoff, (b * kM + q * 256) * 8, 0);
-                d.set(q, __uint_as_float(r.x), __uint_as_float(r.y));
-            }
-        }
-    };
-    auto load_x_part = [&](C16& d, int b, auto part) __attribute__((always_inline)) { load_x_part_from(xs, d, b, part); };
-    auto cvt_x = [&](C16& d) __attribute__((always_inline)) {
-        if constexpr (U8) {
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const unsigned r = __float_as_uint(d.re[q]);
-                d.set(q, (float)(r & 0xffu) - 127.5f, (float)(r >> 8) - 127.5f);
-            }
-        }
-    };
-    auto load_spec_part = [&](C16& d, int b, auto part) __attribute__((always_inline)) {
-        constexpr int G = decltype(part)::value;
-        if (dbg & 32) b = 1;   // ablation: every request hits the same (cache-resident) spectrum
-        if (dbg & 128) return;  // ablation: no spectrum requests
-#pragma unroll
-        for (int j = 2 * G; j < 2 * G + 2; ++j) {
-            const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(ss, soff, (b * 8 + j) * (kThreads * 16), 0);
-            d.set(2 * j, __uint_as_float(w.x), __uint_as_float(w.y));
-            d.set(2 * j + 1, __uint_as_float(w.z), __uint_as_float(w.w));
-        }
-    };
-    auto store_spec = [&](const C16& d, int b) __attribute__((always_inline)) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            // (opaque copies: hipcc otherwise widens these four scalar reads into overlapping 16-byte
-            // loads of the register array, which pins half of it in scratch memory)
-            float e0 = d.re[2 * j], e1 = d.im[2 * j], e2 = d.re[2 * j + 1], e3 = d.im[2 * j + 1];
-            asm volatile("" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3));
-            const u32x4 w = {__float_as_uint(e0), __float_as_uint(e1), __float_as_uint(e2), __float_as_uint(e3)};
-            // The whole byte offset goes into the VGPR offset, soffset = 0.  Root cause of the corruption seen with
-            // an SGPR soffset (round 2, tools/exp_soffset.py + tools/probe/soffset_probe.hip): a store of more
-            // than 64 bits reads its data VGPRs late, so a VALU write to them needs a wait state behind the store
-            // (ISA "required software-inserted wait states").  hipcc 7.2's hazard recognizer waives that wait
-            // state when the store has an SGPR soffset, but on gfx950 the hazard is still there: with soffset in
-            // an SGPR the next group's `v_mov_b32 v3, v86` followed the store of v[2:5] directly and half of all
-            // pair-windows came out wrong on every call; the same stores with two wait states forced behind each
-            // (an asm that keeps e0..e3 live) were right 200 calls out of 200, as is this immediate-soffset form, for
-            // which the compiler inserts the s_nop itself.  (The SGPR form alone is fine: the probe, whose stores
-            // do not reuse their data registers, has no wrong float.)
-            __builtin_amdgcn_raw_buffer_store_b128(w, ss, soff + (b * 8 + j) * (kThreads * 16), 0, 0);
-        }
-    };
-    // forward spectrum of the samples in x, in place (carries the 2^-6 of the TW1 table)
-    auto fwd = [&](C16& xc) __attribute__((always_inline)) {
-        float2* img = (seq & 1) ? img1 : img0;
-        float2 x[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) x[q] = xc.get(q);
-        mul_w32_odd(x);            // odd sub-transform input x*W32^q (W_L^u is folded into tw1)
-        dft16(x);
-        mul_tw1(x, tw1);
-        if (!(dbg & 8)) xchg_a_write(img, x, t);
-        barrier_hook(false);
-        if (!(dbg & 8)) xchg_b_read(img, x, t);
-        dft16(x);
-#ifdef RMX_TW2_LDS
-        const float4 r0 = tw2row[0], r1 = tw2row[1];   // ahead of the exchange reads (see dft16_tw_row_l1)
-#endif
-        if (!(dbg & 4)) {
-        xchg_bc_write_b(img, x, t);
-        wave_lds_order();
-        xchg_bc_read_c(img, x, t);
-        }
-#ifndef RMX_TW2_LDS
-        dft16_tw<true>(x, tw2r);
-#else
-        dft16_tw_row(x, tw2row, r0, r1);   // W_256^(n0*k1) as pre-twiddle of the last pass
-#endif
-#pragma unroll
-        for (int q = 0; q < 16; ++q) xc.set(q, x[q].x, x[q].y);   // (scaled by 2^-6 through the TW1 table)
-        ++seq;
-    };
-    // One pair = two halves around its only workgroup barrier.
-    //   h1  conj-multiply merged into the role-C pass, wave-local exchange, role-B pass, stores into
-    //       exchange image `tr & 1` (this wave's own regions); `prefetch(part)` is called four times
-    //       after the last read of a and s (their registers may be reloaded there)
-    //   h2  reads image `tr & 1` (all waves' regions), role-A pass, last radix-2, |.|^2, peak records
-    // h2 of pair n and h1 of pair n+1 sit between the same two barriers and do not depend on each
-    // other (different images, disjoint registers), so the two waves that share a SIMD can run them in
-    // opposite order: see the phase-2 loop.
-    auto pair_h1 = [&](const C16& a, const C16& s, int tr, auto prefetch) __attribute__((always_inline)) {
-        float2* img = (tr & 1) ? img1 : img0;
-        float2 v[16];
-        // R = X_j conj(X_i), (im,re)-swapped == swap(X_j) * X_i: merged into the first radix-16 pass
-#pragma unroll
-        for (int q = 0; q < 16; ++q) v[q] = make_float2(s.im[q], s.re[q]);
-        dft16_tw_l1<false>(v, a);                // k2 -> n0   (role C), layer 1: the last reads of a and s
-#pragma unroll
-        for (int q = 0; q < 16; q += 4)          // pin: the requests below must follow the reads above
-            asm volatile("" : "+v"(v[q].x), "+v"(v[q].y), "+v"(v[q + 1].x), "+v"(v[q + 1].y), "+v"(v[q + 2].x),
-                         "+v"(v[q + 2].y), "+v"(v[q + 3].x), "+v"(v[q + 3].y));
-        __builtin_amdgcn_sched_barrier(0);
-        {   // layer 2 group by group: each group's outputs go to the wave-local image at once, and a
-            // quarter of the next spectra is requested behind it
-            float2* wb = img + (u >> 4) * kBcHalf + (u & 15) * kBcRow + p;
-            dft16_layer2_emit(v, [&](auto kac, const float2& x0, const float2& x1, const float2& x2, const float2& x3)
-                                     __attribute__((always_inline)) {
-                constexpr int ka = decltype(kac)::value;
-                if (!(dbg & 4)) {
-                    wb[2 * ka] = make_float2(x0.x, x0.y);
-                    wb[2 * (ka + 4)] = make_float2(x1.x, x1.y);
-                    wb[2 * (ka + 8)] = make_float2(x2.x, x2.y);
-                    wb[2 * (ka + 12)] = make_float2(x3.x, x3.y);
-                }
-                if (!(dbg & 16)) prefetch(kac);
-            });
-        }
-#ifdef RMX_TW2_LDS
-        const float4 r0 = tw2row[0], r1 = tw2row[1];   // ahead of the exchange reads (see dft16_tw_row_l1)
-#endif
-        if (!(dbg & 4)) {
-            wave_lds_order();
-            xchg_bc_read_b(img, v, t);
-        }
-#ifndef RMX_TW2_LDS
-        dft16_tw_l1<true>(v, tw2r);
-#else
-        dft16_tw_row_l1(v, tw2row, r0, r1);      // W_256^(n0*k1), k1 -> n1   (role B), layer 1
-#endif
-        {
-            float2* xb = img + (u >> 4) * kBcHalf + (u & 15) * 2 + p;   // own half-wave regions
-            dft16_layer2_emit(v, [&](auto kac, const float2& x0, const float2& x1, const float2& x2, const float2& x3)
-                                     __attribute__((always_inline)) {
-                constexpr int ka = decltype(kac)::value;
-                if (!(dbg & 8)) {
-                    xb[ka * 32] = make_float2(x0.x, x0.y);
-                    xb[(ka + 4) * 32] = make_float2(x1.x, x1.y);
-                    xb[(ka + 8) * 32] = make_float2(x2.x, x2.y);
-                    xb[(ka + 12) * 32] = make_float2(x3.x, x3.y);
-                }
-            });
-        }
-    };
-    auto pair_h2 = [&](int tr, int out_idx) __attribute__((always_inline)) {
-        const float2* img = (tr & 1) ? img1 : img0;
-        const int rb = npair & (kResSlots - 1);
-        float2 v[16];
-        if (!(dbg & 8)) xchg_a_read(img, v, t);
-        dft16_tw<false>(v, tw1);                 // W_M^(u*k0) [* W_L^u odd], k0 -> n2   (role A)
-        mul_w32_odd(v);                          // odd lanes: * W32^q
-        // last radix-2 stage across the lane pair, up to a sign that |.| does not see:
-        // even lane e + o' = r[n], odd lane o' - e = -r[n+M]
-        pair_fmac8(v[0].x, v[0].y, v[1].x, v[1].y, v[2].x, v[2].y, v[3].x, v[3].y, sgn);
-        pair_fmac8(v[4].x, v[4].y, v[5].x, v[5].y, v[6].x, v[6].y, v[7].x, v[7].y, sgn);
-        pair_fmac8(v[8].x, v[8].y, v[9].x, v[9].y, v[10].x, v[10].y, v[11].x, v[11].y, sgn);
-        pair_fmac8(v[12].x, v[12].y, v[13].x, v[13].y, v[14].x, v[14].y, v[15].x, v[15].y, sgn);
-        float mag[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) mag[q] = fmaf(v[q].x, v[q].x, v[q].y * v[q].y);
-        if (p && u == 0) mag[0] = -1.0f;         // lag -M is not part of the 'full' output
-        if (dbg & 2) {
-            float s = 0;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) s += mag[q];
-            if (s == 12345.678f) lag_int[0] = 1;
-            ++npend; ++npair;
-            return;
-        }
-        if (is_halo) {
-            float4* hp = reinterpret_cast<float4*>(halo + ((rb * 8 + wave) * 4 + hl) * 16);
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4)
-                hp[q4] = make_float4(mag[4 * q4], mag[4 * q4 + 1], mag[4 * q4 + 2], mag[4 * q4 + 3]);
-        }
-        float tmax = mag[0];
-#pragma unroll
-        for (int q = 1; q < 16; ++q) tmax = fmaxf(tmax, mag[q]);
-        // lowest slot holding the max: four independent select chains
-        int qa = 16, qb = 16, qc = 16, qd = 16;
-        argsel4<12>(qa, qb, qc, qd, mag[12], mag[13], mag[14], mag[15], tmax);   // descending: lower slots win
-        argsel4<8>(qa, qb, qc, qd, mag[8], mag[9], mag[10], mag[11], tmax);
-        argsel4<4>(qa, qb, qc, qd, mag[4], mag[5], mag[6], mag[7], tmax);
-        argsel4<0>(qa, qb, qc, qd, mag[0], mag[1], mag[2], mag[3], tmax);
-        const int qsel = min(min(qa, qb), min(qc, qd));
-        const int kq = kbase + qsel * 256;
-        const float wmax = wave_max_f32(tmax);
-        const int kw = wave_min_i32(tmax == wmax ? kq : 0x7fffffff);
-        // the winner's neighbours k*-1, k*+1 live in lanes l*-2, l*+2 (same slot) when those exist
-        int ts, qs;
-        k_to_owner(kw, ts, qs);
-        const int ls = ts & 63;
-        // qs is wave-uniform (it comes out of the wave reductions): one indexed register read
-        // (s_set_gpr_idx) instead of a 16-way select chain
-        typedef float f16v __attribute__((ext_vector_type(16)));
-        const f16v mv = {mag[0], mag[1], mag[2],  mag[3],  mag[4],  mag[5],  mag[6],  mag[7],
-                         mag[8], mag[9], mag[10], mag[11], mag[12], mag[13], mag[14], mag[15]};
-        const float sel = mv[__builtin_amdgcn_readfirstlane(qs)];
-        const int seli = __builtin_bit_cast(int, sel);
-        const float tapm = ls >= 2 ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(seli, ls >= 2 ? ls - 2 : 0)) : -2.0f;
-        const float tapp = ls <= 61 ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(seli, ls <= 61 ? ls + 2 : 63)) : -2.0f;
-        if (lane == 0) {
-            const u32x4 rec = {__float_as_uint(wmax), (unsigned)kw, __float_as_uint(tapm), __float_as_uint(tapp)};
-            *reinterpret_cast<u32x4*>(red + rb * 8 + wave) = rec;
-            if (wave == 0) oidx[rb] = out_idx;
-        }
-        ++npend;
-        ++npair;
-    };
-    auto pair = [&](const C16& a, const C16& s, int out_idx, auto prefetch) __attribute__((always_inline)) {
-        pair_h1(a, s, seq, prefetch);
-        barrier_hook(false);                     // the pair's only barrier
-        pair_h2(seq, out_idx);
-        ++seq;
-    };
-    auto out_of = [&](int i, int j) -> int { return i * B - (i * (i + 1)) / 2 + (j - i - 1); };
-
-    // ---- anchor 0: X_0 goes straight into the anchor registers (never stored); every other X_e is
-    // transformed once, stored once for the later anchors, and used at once from registers for (0,e)
-    load_x(sa, 0);
-    if (B > 1) load_x(sb, 1);          // sb is free: X_1's samples travel while X_0 is transformed
-    cvt_x(sa);
-    fwd(sa);
-    // (the last buoy is peeled off the loop: its pair requests spectra instead of samples; with both
-    // request kinds in one loop body the compiler's waitcnt bookkeeping merges their destination
-    // registers across the back edge)
-    for (int e = 1; e + 1 < B; ++e) {
-        cvt_x(sb);
-        fwd(sb);
-        store_spec(sb, e);
-        pair(sa, sb, out_of(0, e), [&](auto part) __attribute__((always_inline)) { load_x_part(sb, e + 1, part); });
-    }
-    if (B > 1) {
-        cvt_x(sb);
-        fwd(sb);
-        store_spec(sb, B - 1);
-        pair(sa, sb, out_of(0, B - 1), [&](auto part) __attribute__((always_inline)) {
-            if (B > 2) {               // next anchor 1 streams downwards from B-1: X_{B-1} is L2-hot
-                load_spec_part(sa, 1, part);
-                load_spec_part(sb, B - 1, part);
-            }
-        });
-    }
-    // ---- anchors 1..B-2: the stream direction alternates (odd anchors walk j down, even ones up), so
-    // the first spectra an anchor streams are the ones the previous anchor touched last (L2 hits).
-    // Between two barriers sit h2 of pair m and h1 of pair m+1, which are independent: waves 0-3 run
-    // them in that order and waves 4-7 (the second wave of each SIMD) in the opposite order, so that
-    // one wave's LDS / barrier / DPP-chain stalls fall on the other's butterfly arithmetic instead of
-    // on the same stalls (all eight waves are otherwise barrier-aligned in lockstep).
-    {
-        const int M2 = (B - 1) * (B - 2) / 2;            // pairs of this phase
-        // SIMD pairs {a, a+2} vs {a+1, a+3} (stag 1): measured best of the splits; 0 = nobody, 5 = everybody late
-        // (2: odd waves = SIMDs 1, 3; 3: the second wave of every SIMD; 4: one wave of every SIMD, alternating between SIMDs)
-        const bool late_h2 = stag == 1 ? ((wave >> 1) & 1) : stag == 2 ? (wave & 1) : stag == 3 ? (wave >> 2) :
-                             stag == 4 ? ((wave ^ (wave >> 2)) & 1) : (stag == 5);
-        auto j_of = [&](int i, int s) -> int { return (i & 1) ? (B - 1 - s) : (i + 1 + s); };
-        int ci = 1, cs = 0;                              // pair m     (anchor, position in its run)
-        int ni = 1, ns = 1;                              // pair m + 1
-        if (ns >= B - 1 - ni) { ++ni; ns = 0; }
-        auto h1_of = [&](int hi, int hs, int tr) __attribute__((always_inline)) {
-            // spectra for the pair after (hi, hs) are requested here
-            int pi = hi, ps = hs + 1;
-            if (ps >= B - 1 - pi) { ++pi; ps = 0; }
-            const bool valid = pi + 1 < B;
-            const bool new_anchor = pi != hi;
-            const int pj = j_of(pi, ps);
-            pair_h1(sa, sb, tr, [&](auto part) __attribute__((always_inline)) {
-                if (valid) {
-                    if (new_anchor) load_spec_part(sa, pi, part);
-                    load_spec_part(sb, pj, part);
-                }
-            });
-        };
-        if (M2 > 0) h1_of(ci, cs, seq);
-        for (int m = 0; m < M2; ++m) {
-            barrier_hook(false);
-            const bool has_next = m + 1 < M2;
-            const int out_idx = out_of(ci, j_of(ci, cs));
-            if (late_h2) {
-                if (has_next) h1_of(ni, ns, seq + 1);
-                pair_h2(seq, out_idx);
-            } else {
-                pair_h2(seq, out_idx);
-                if (has_next) h1_of(ni, ns, seq + 1);
-            }
-            ++seq;
-            ci = ni; cs = ns;
-            ++ns;
-            if (ns >= B - 1 - ni) { ++ni; ns = 0; }
-        }
-    }
-    seq = 0;   // any wave may resolve the last pairs; take wave 0
-    barrier_hook(true);
-    }   // next window of this workgroup
-}
 
 // k_win on packed fp32 (winpk.hpp): same protocol, same resolve routine
 template <bool U8>
@@ -1253,35 +709,6 @@ static int fail(rmx_ctx* c, int code, const char* fmt, ...) {
 
 static bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
 
-static constexpr int kTw1ScaleLog2 = 6;                       // spectra carry 2^-6 (L = 2^13: sqrt(L) rounded down)
-static constexpr double kTw1Scale = 1.0 / (1 << kTw1ScaleLog2);
-static void build_tables(std::vector<float4>& tw1, std::vector<float2>& tw2) {
-    const double two_pi = 6.283185307179586476925286766559;
-    tw1.resize(8 * kThreads);
-    std::vector<float2> t1(16 * kThreads);
-    for (int t = 0; t < kThreads; ++t) {
-        const int p = t & 1, u = t >> 1;
-        for (int k0 = 0; k0 < 16; ++k0) {
-            // W_M^(u*k0) * (p ? W_L^u : 1), W_n = exp(-2*pi*i/n)
-            double ang = -two_pi * (double)((u * k0) % kM) / (double)kM;
-            if (p) ang += -two_pi * (double)u / (double)kL;
-            // the power-of-two scale of the forward spectra rides on this table (exact): the forward
-            // transform multiplies by it once, the inverse once more (undone in out_scale)
-            t1[k0 * kThreads + t] = make_float2((float)(std::cos(ang) * kTw1Scale), (float)(std::sin(ang) * kTw1Scale));
-        }
-    }
-    for (int j = 0; j < 8; ++j)
-        for (int t = 0; t < kThreads; ++t) {
-            const float2 a = t1[(2 * j) * kThreads + t], b = t1[(2 * j + 1) * kThreads + t];
-            tw1[j * kThreads + t] = make_float4(a.x, a.y, b.x, b.y);
-        }
-    tw2.resize(256);
-    for (int a = 0; a < 16; ++a)
-        for (int b = 0; b < 16; ++b) {
-            const double ang = -two_pi * (double)((a * b) % 256) / 256.0;
-            tw2[a * 16 + b] = make_float2((float)std::cos(ang), (float)std::sin(ang));
-        }
-}
 
 // tables of k_win8 (win8.hpp; the same values tools/model_win8.py checks against numpy's FFT)
 static void build_tables8(std::vector<float4>& tw1, std::vector<float2>& tb, std::vector<float2>& tc) {
