@@ -14,6 +14,12 @@
  *         c   = correlate(x[w][j], x[w][i], mode='full', method='fft')   (complex64, 2N-1 lags)
  *         m   = |c|                                                     (float32)
  *         k   = argmax m   (ties -> lowest k)        lag_int  = k - (N-1)
+ *               (The kernels search the maximum of |c|^2 and take the square root of the three taps only.  sqrt is
+ *               monotonic, so the two orders agree except in one class of inputs: two lags whose |c|^2 differ in the
+ *               last bit but whose float32 |c| round to the SAME value.  numpy then sees a tie and takes the lower
+ *               index; the kernels take the lag with the larger square.  Such pairs are one float32 ulp apart in
+ *               magnitude -- below what two float32 FFTs agree on -- and cannot occur when the two values are
+ *               bit-identical, which is the case the tie rule is tested on.)
  *         d   = 3-point parabolic vertex offset      lag_frac = d  (0 at the edges / flat top)
  *         peak = m[k]
  *     lag = lag_int + lag_frac samples = delay(buoy j) - delay(buoy i)   (sign of

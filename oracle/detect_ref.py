@@ -11,8 +11,13 @@ Literal restatement of the reference's detector (``buoy_node.py:401-433``, the s
     floor  = median(P);  snr = P[peak] - floor;  confidence = min(max(snr / 20, 0), 1)
     report a peak unless |f - f_centre| < 10 kHz (``:419``) or confidence < 0.3 (``:430``)
 
-``buoy_node.py`` itself cannot be imported here (ModuleNotFoundError: websockets), so no fixture comes
-from the reference's own code: the definition is pinned by the library calls above.
+Pinning.  ``buoy_node.py`` itself cannot be imported in the build container (ModuleNotFoundError: websockets), but
+the reference's ``signal_analyzer.py`` holds the same decode (``load_iq_data``, ``:14-41``) and the same dB
+spectrum (``analyze_spectrum``, ``:47-86``) and does import: ``tests/golden/make_golden.py --sa-only`` records their
+outputs on synthetic captures (``tests/golden/signal_analyzer.npz``), and ``tests/test_oracle_golden.py`` checks
+``power_spectrum_db`` (and ``xcorr_ref.decode_u8_iq``) against them.  The peak rule beyond the spectrum --
+``find_peaks(height, distance=10)``, the median floor, the confidence cut -- is the reference's literal library
+calls (checked statement by statement in ``tests/test_detect.py::test_oracle_is_the_reference_call_sequence``).
 """
 from __future__ import annotations
 

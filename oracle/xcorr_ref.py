@@ -215,6 +215,19 @@ def peak_margin(x_i: np.ndarray, x_j: np.ndarray) -> float:
     return float((top - second) / top) if top > 0 else 0.0
 
 
+def peak_top2(x_i: np.ndarray, x_j: np.ndarray):
+    """(margin, lag of the largest magnitude sample, lag of the second largest): the two candidates between which
+    float32 rounding of a different FFT may decide when the margin is below ~1e-6."""
+    m = np.abs(xcorr_full_scipy(x_i, x_j)).astype(np.float64)
+    n = x_i.shape[-1]
+    k = int(np.argmax(m))
+    top = m[k]
+    m[k] = -1.0
+    k2 = int(np.argmax(m))
+    margin = float((top - m[k2]) / top) if top > 0 else 0.0
+    return margin, k - (n - 1), k2 - (n - 1)
+
+
 def lag_to_tdoa(lag_samples: float, sample_rate_hz: float):
     """S7: (time_difference_ns:int, distance_difference_m:float), tdoa_processor.py:166-170."""
     t = lag_samples / sample_rate_hz

@@ -130,6 +130,20 @@ __device__ __forceinline__ void resolve_batch(int lane, const float4* red, const
     }
 }
 
+#ifdef RMX_KWIN_STAMPS
+// diagnostic build (tools/probe/kwin_bench.hip -DRMX_KWIN_STAMPS): shader-clock stamps of workgroup's wave 0 at the phase
+// boundaries of every window it processes; no stamp exists in the product build
+__device__ long long rmx_stamps[256 * 64 * 4];
+__device__ int rmx_stamps_vm[256 * 64 * 8];   // per wave: ticks spent in the vmcnt wait at the head of h1, summed over the window's pairs
+#define RMX_STAMP(slot)                                                                              \
+    do {                                                                                             \
+        if (t == 0 && (wl / (int)gridDim.x) < 64)                                                    \
+            rmx_stamps[((int)blockIdx.x * 64 + wl / (int)gridDim.x) * 4 + (slot)] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define RMX_STAMP(slot) do { } while (0)
+#endif
+
 // Schedule of one window (all pairs i<j of B buoys; the anchor spectrum X_i is resident in registers,
 // X_j streams one pair ahead):
 //   anchor 0      X_0 is transformed straight into the anchor registers (never stored); every further
@@ -202,12 +216,15 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
     int seq = 0;         // transform counter: selects the exchange image
     int npair = 0;       // pair counter: selects the record slot (ring of kResSlots)
     int npend = 0;       // pairs whose records await a resolve
+#ifdef RMX_KWIN_STAMPS
+    int stamp_vm = 0;
+#endif
 
 
     auto barrier_hook = [&](bool flush) __attribute__((always_inline)) {
         if (!(dbg & 1)) __syncthreads();
         if (npend == kResBatch || (flush && npend > 0)) {
-            if (!(dbg & 2) && wave == (seq & 7))
+            if (!(dbg & 2) && !(dbg & 256) && wave == (seq & 7))
                 resolve_batch(lane, red, halo, oidx, (npair - npend) & (kResSlots - 1), npend, obase, out_scale, lag_int,
                               lag_frac, peak);
             npend = 0;
@@ -264,13 +281,18 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
     auto load_x_part_from = [&](const __amdgpu_buffer_rsrc_t& rs, C16& d, int b, auto part) __attribute__((always_inline)) {
         constexpr int G = decltype(part)::value;
         if (dbg & 64) return;   // ablation: no window-sample requests
+#ifndef RMX_KWIN_NO_SPREAD
+        constexpr int Q0 = 2 * G, Q1 = 2 * G + 2;   // eighths: issued from the groups of BOTH butterfly layers of h1
+#else
+        constexpr int Q0 = 4 * G, Q1 = 4 * G + 4;
+#endif
         if constexpr (U8) {
 #pragma unroll
-            for (int q = 4 * G; q < 4 * G + 4; ++q)
+            for (int q = Q0; q < Q1; ++q)
                 d.re[q] = __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs, xoff, (b * kM + q * 256) * 2, 0));
         } else {
 #pragma unroll
-            for (int q = 4 * G; q < 4 * G + 4; ++q) {
+            for (int q = Q0; q < Q1; ++q) {
                 const u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(rs, xoff, (b * kM + q * 256) * 8, 0);
                 d.set(q, __uint_as_float(r.x), __uint_as_float(r.y));
             }
@@ -290,8 +312,13 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
         constexpr int G = decltype(part)::value;
         if (dbg & 32) b = 1;   // ablation: every request hits the same (cache-resident) spectrum
         if (dbg & 128) return;  // ablation: no spectrum requests
+#ifndef RMX_KWIN_NO_SPREAD
+        constexpr int J0 = G, J1 = G + 1;
+#else
+        constexpr int J0 = 2 * G, J1 = 2 * G + 2;
+#endif
 #pragma unroll
-        for (int j = 2 * G; j < 2 * G + 2; ++j) {
+        for (int j = J0; j < J1; ++j) {
             const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(ss, soff, (b * 8 + j) * (kThreads * 16), 0);
             d.set(2 * j, __uint_as_float(w.x), __uint_as_float(w.y));
             d.set(2 * j + 1, __uint_as_float(w.z), __uint_as_float(w.w));
@@ -350,7 +377,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
     };
     // One pair = two halves around its only workgroup barrier.
     //   h1  conj-multiply merged into the role-C pass, wave-local exchange, role-B pass, stores into
-    //       exchange image `tr & 1` (this wave's own regions); `prefetch(part)` is called four times
+    //       exchange image `tr & 1` (this wave's own regions); `prefetch(part)` is called eight times,
+    //       from the groups of both butterfly layers (parts 0-3 behind the role-C pass, 4-7 behind the role-B pass: one
+    //       16-byte request per part instead of bursts of two, tools/probe/kwin_bench.hip: -0.6 %), always
     //       after the last read of a and s (their registers may be reloaded there)
     //   h2  reads image `tr & 1` (all waves' regions), role-A pass, last radix-2, |.|^2, peak records
     // h2 of pair n and h1 of pair n+1 sit between the same two barriers and do not depend on each
@@ -359,6 +388,14 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
     auto pair_h1 = [&](const C16& a, const C16& s, int tr, auto prefetch) __attribute__((always_inline)) {
         float2* img = (tr & 1) ? img1 : img0;
         float2 v[16];
+#ifdef RMX_KWIN_STAMPS
+        {   // how long does this wave wait for the spectra it requested a pair ahead?
+            const long long c0 = __builtin_readcyclecounter();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const long long c1 = __builtin_readcyclecounter();
+            stamp_vm += (int)(c1 - c0);
+        }
+#endif
         // R = X_j conj(X_i), (im,re)-swapped == swap(X_j) * X_i: merged into the first radix-16 pass
 #pragma unroll
         for (int q = 0; q < 16; ++q) v[q] = make_float2(s.im[q], s.re[q]);
@@ -406,6 +443,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
                     xb[(ka + 8) * 32] = make_float2(x2.x, x2.y);
                     xb[(ka + 12) * 32] = make_float2(x3.x, x3.y);
                 }
+#ifndef RMX_KWIN_NO_SPREAD
+                if (!(dbg & 16)) prefetch(std::integral_constant<int, ka + 4>{});
+#endif
             });
         }
     };
@@ -434,7 +474,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
             ++npend; ++npair;
             return;
         }
-        if (is_halo) {
+        if (is_halo && !(dbg & 512)) {
             float4* hp = reinterpret_cast<float4*>(halo + ((rb * 8 + wave) * 4 + hl) * 16);
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4)
@@ -443,6 +483,58 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
         float tmax = mag[0];
 #pragma unroll
         for (int q = 1; q < 16; ++q) tmax = fmaxf(tmax, mag[q]);
+#ifndef RMX_KWIN_OLD_PEAK
+        // Lowest slot holding the lane's max (four select chains, descending so that lower slots win), with the four
+        // row steps of the wave maximum issued BETWEEN the chains' groups: the DPP steps depend on each other, the
+        // groups do not depend on them, so neither the 2 wait states in front of a DPP read nor the steps' latency
+        // are ever waited for.  One asm statement (hipcc separates consecutive statements by s_nop).
+        int qa = 16, qb = 16, qc = 16, qd = 16;
+        float wrow;
+        {
+            unsigned long long k0, k1, k2, k3;
+#define RMX_AS4(M0, M1, M2, M3, Q)                                                        \
+    "v_cmp_eq_f32_e64 %[k0], %[" #M0 "], %[t]\n\tv_cmp_eq_f32_e64 %[k1], %[" #M1 "], %[t]\n\t" \
+    "v_cmp_eq_f32_e64 %[k2], %[" #M2 "], %[t]\n\tv_cmp_eq_f32_e64 %[k3], %[" #M3 "], %[t]\n\t" \
+    "v_cndmask_b32_e64 %[qa], %[qa], " #Q ", %[k0]\n\tv_cndmask_b32_e64 %[qb], %[qb], " #Q "+1, %[k1]\n\t" \
+    "v_cndmask_b32_e64 %[qc], %[qc], " #Q "+2, %[k2]\n\tv_cndmask_b32_e64 %[qd], %[qd], " #Q "+3, %[k3]\n\t"
+            asm volatile(RMX_AS4(mc, md, me, mf, 12)
+                         "v_max_f32_dpp %[w], %[t], %[t] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                         RMX_AS4(m8, m9, ma, mb, 8)
+                         "v_max_f32_dpp %[w], %[w], %[w] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                         RMX_AS4(m4, m5, m6, m7, 4)
+                         "v_max_f32_dpp %[w], %[w], %[w] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                         RMX_AS4(m0, m1, m2, m3, 0)
+                         "v_max_f32_dpp %[w], %[w], %[w] row_mirror row_mask:0xf bank_mask:0xf"
+                         : [qa] "+v"(qa), [qb] "+v"(qb), [qc] "+v"(qc), [qd] "+v"(qd), [w] "=&v"(wrow), [k0] "=&s"(k0),
+                           [k1] "=&s"(k1), [k2] "=&s"(k2), [k3] "=&s"(k3)
+                         : [t] "v"(tmax), [m0] "v"(mag[0]), [m1] "v"(mag[1]), [m2] "v"(mag[2]), [m3] "v"(mag[3]),
+                           [m4] "v"(mag[4]), [m5] "v"(mag[5]), [m6] "v"(mag[6]), [m7] "v"(mag[7]), [m8] "v"(mag[8]),
+                           [m9] "v"(mag[9]), [ma] "v"(mag[10]), [mb] "v"(mag[11]), [mc] "v"(mag[12]), [md] "v"(mag[13]),
+                           [me] "v"(mag[14]), [mf] "v"(mag[15]));
+#undef RMX_AS4
+        }
+        const int qsel = min(min(qa, qb), min(qc, qd));
+        const int kq = kbase + qsel * 256;
+        const int wi = __builtin_bit_cast(int, wrow);   // every lane: the max of its row of 16
+        const float wmax = fmaxf(fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(wi, 0)),
+                                       __builtin_bit_cast(float, __builtin_amdgcn_readlane(wi, 16))),
+                                 fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(wi, 32)),
+                                       __builtin_bit_cast(float, __builtin_amdgcn_readlane(wi, 48))));
+        // which lane holds it?  One lane almost always: its index and slot come over by readlane.  Several lanes (an
+        // exact tie between lanes): the lowest 'full' index decides, found by the wave minimum as before.
+        const unsigned long long hit = __ballot(tmax == wmax);
+        int kw, ls, qs;
+        if (__popcll(hit) == 1) {
+            ls = __ffsll((long long)hit) - 1;
+            kw = __builtin_amdgcn_readlane(kq, ls);
+            qs = __builtin_amdgcn_readlane(qsel, ls);
+        } else {
+            kw = wave_min_i32(tmax == wmax ? kq : 0x7fffffff);
+            int ts;
+            k_to_owner(kw, ts, qs);
+            ls = ts & 63;
+        }
+#else
         // lowest slot holding the max: four independent select chains
         int qa = 16, qb = 16, qc = 16, qd = 16;
         argsel4<12>(qa, qb, qc, qd, mag[12], mag[13], mag[14], mag[15], tmax);   // descending: lower slots win
@@ -457,6 +549,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
         int ts, qs;
         k_to_owner(kw, ts, qs);
         const int ls = ts & 63;
+#endif
         // qs is wave-uniform (it comes out of the wave reductions): one indexed register read
         // (s_set_gpr_idx) instead of a 16-way select chain
         typedef float f16v __attribute__((ext_vector_type(16)));
@@ -484,6 +577,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
 
     // ---- anchor 0: X_0 goes straight into the anchor registers (never stored); every other X_e is
     // transformed once, stored once for the later anchors, and used at once from registers for (0,e)
+    RMX_STAMP(0);
     load_x(sa, 0);
     if (B > 1) load_x(sb, 1);          // sb is free: X_1's samples travel while X_0 is transformed
     cvt_x(sa);
@@ -508,6 +602,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
             }
         });
     }
+    RMX_STAMP(1);
     // ---- anchors 1..B-2: the stream direction alternates (odd anchors walk j down, even ones up), so
     // the first spectra an anchor streams are the ones the previous anchor touched last (L2 hits).
     // Between two barriers sit h2 of pair m and h1 of pair m+1, which are independent: waves 0-3 run
@@ -556,6 +651,10 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
             if (ns >= B - 1 - ni) { ++ni; ns = 0; }
         }
     }
+    RMX_STAMP(2);
+#ifdef RMX_KWIN_STAMPS
+    if (lane == 0 && (wl / (int)gridDim.x) < 64) rmx_stamps_vm[((int)blockIdx.x * 64 + wl / (int)gridDim.x) * 8 + wave] = stamp_vm;
+#endif
     seq = 0;   // any wave may resolve the last pairs; take wave 0
     barrier_hook(true);
     }   // next window of this workgroup

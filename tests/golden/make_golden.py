@@ -21,6 +21,11 @@ It imports ``/root/reference/tdoa_processor.py`` and records
   detections of the reference's own ``main()`` example (``tdoa_processor.py:475-490``): pins the
   pair order, the sign (buoy2 - buoy1) and the ns -> metres conversion.
 
+* ``signal_analyzer.npz`` -- the reference's own uint8 decode and dB spectrum: ``load_iq_data`` (``signal_analyzer.py:14-41``,
+  the same three statements as ``buoy_node.py:392-398``) and ``analyze_spectrum`` (``:47-86``: ``np.fft.fft`` ->
+  ``fftshift`` -> ``20 log10(|X| + 1e-12)`` -> ``scipy.signal.find_peaks``) of the imported ``/root/reference/signal_analyzer.py``
+  on synthetic rtl_sdr captures written to a temporary ``.bin`` (``make_signal_analyzer``); ``--sa-only`` regenerates just this.
+
 Only arrays / JSON are written: no reference source text.
 """
 import hashlib
@@ -187,11 +192,60 @@ def make_triangulation(ref):
                        scenarios=out), f, indent=1)
 
 
+def make_signal_analyzer():
+    """Decode + dB spectrum fixture from the reference's signal_analyzer.py (a5 / a6 of SURVEY.md section 8a)."""
+    import contextlib
+    import io
+    import tempfile
+    os.environ.setdefault("MPLBACKEND", "Agg")
+    spec = importlib.util.spec_from_file_location("ref_signal_analyzer", "/root/reference/signal_analyzer.py")
+    sa = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sa)
+    rng = np.random.default_rng(4242)
+    fs, fc_mhz = 2.048e6, 121.5                      # buoy_node.py:363 sample rate; an aviation-band centre
+    out = {}
+    raws, decs, specs, freqs, peaks = [], [], [], [], []
+    for n in (4096, 16384):                          # 16384 = the capture length of buoy_node.py:364
+        t = np.arange(n)
+        x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 5.0
+        for f, a in ((0.11, 55.0), (-0.23, 30.0), (0.37, 18.0)):
+            x += a * np.exp(2j * np.pi * (f * t + rng.uniform()))
+        raw = np.empty(2 * n, np.uint8)
+        raw[0::2] = np.clip(np.floor(x.real + 128.0), 0, 255)
+        raw[1::2] = np.clip(np.floor(x.imag + 128.0), 0, 255)
+        # every byte value once more at the end of the larger capture: the decode is pinned on all 256 of them
+        if n == 16384:
+            raw[-512:-256] = np.arange(256, dtype=np.uint8)
+            raw[-256:] = np.arange(255, -1, -1, dtype=np.uint8)
+        with tempfile.TemporaryDirectory() as d:
+            path = os.path.join(d, "iq_capture_121.5MHz_test.bin")   # the naming of sdr_capture.py:24-45
+            raw.tofile(path)
+            with contextlib.redirect_stdout(io.StringIO()):
+                dec, fs_out = sa.load_iq_data(path, sample_rate=int(fs))
+                fr, ps, pk = sa.analyze_spectrum(dec, fs_out, fc_mhz)
+        assert fs_out == int(fs)
+        key = "n%d" % n
+        out[key + "_raw_u8"] = raw
+        out[key + "_decoded"] = dec
+        out[key + "_power_spectrum_db"] = ps          # fftshift order, as the reference returns it
+        bins = np.searchsorted(fr, pk)                 # the reference returns peak FREQUENCIES; keep their shifted bins
+        assert np.array_equal(fr[bins], pk)
+        out[key + "_freq_first_last_mhz"] = np.array([fr[0], fr[-1]])
+        out[key + "_peak_bins_shifted"] = bins.astype(np.int32)
+        print("signal_analyzer n=%d: decoded %s, spectrum %s, %d peaks" % (n, dec.dtype, ps.dtype, len(pk)))
+    out["sample_rate_hz"] = np.float64(fs)
+    out["center_freq_mhz"] = np.float64(fc_mhz)
+    np.savez_compressed(os.path.join(HERE, "signal_analyzer.npz"), **out)
+
+
 def checksum(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
 def main():
+    if "--sa-only" in sys.argv:
+        make_signal_analyzer()
+        return
     ref = load_reference()
     if "--caf-only" in sys.argv:
         make_caf(ref)

@@ -1,10 +1,10 @@
 """Parity of the HIP path (through the C ABI) against the oracle and the golden fixtures.
 Bars: integer lag bit-exact; |lag - lag_ref| <= 1e-5 * max(|lag_ref|, 1); peak rtol 1e-5.
 
-Where two candidate peaks are closer than 1e-5 relative in the *oracle's own* magnitudes the integer
-argmax is decided by float32 rounding order of the FFT used (pocketfft vs ours); such pair-windows
-are reported and accepted only if the GPU pick is one of those candidates (none occur in the
-committed fixtures: their smallest margin is 2.3e-3)."""
+Where the oracle's own two largest magnitudes are closer than 1e-5 relative the integer argmax is decided by the
+float32 rounding of the FFT used (pocketfft vs ours): such a pair-window is accepted only if the GPU's lag IS the
+oracle's second candidate (`_assert_parity(..., margin, second)`; the seeded sweeps compute both with
+`oracle.peak_top2`).  The committed fixtures get no such exception: their smallest margin is 2.3e-3."""
 import os
 
 import numpy as np
@@ -27,12 +27,28 @@ def xc():
     return xcorr
 
 
-def _assert_parity(li, lf, pk, ri, rf, rp, margin=None):
+def _top2(iq, plist):
+    """(margin [W][P], lag of the oracle's second-largest magnitude sample [W][P]) for _assert_parity"""
+    W = iq.shape[0]
+    m = np.zeros((W, len(plist)))
+    second = np.zeros((W, len(plist)), np.int64)
+    for w in range(W):
+        for q, (i, j) in enumerate(plist):
+            m[w, q], _, second[w, q] = orc.peak_top2(iq[w, i], iq[w, j])
+    return m, second
+
+
+def _assert_parity(li, lf, pk, ri, rf, rp, margin=None, second=None):
+    """Integer lags bit-exact.  The one accepted exception: the oracle's own two largest magnitudes are within 1e-5
+    of each other (`margin`) AND the GPU's lag is the oracle's second candidate (`second`) -- then two correct float32
+    FFTs may order the pair differently.  Without `second` (the committed fixtures, whose smallest margin is 2.3e-3)
+    there is no exception at all."""
     ref = ri + rf
     got = li + lf.astype(np.float64)
     bad = li != ri
-    if margin is not None:
-        assert not np.any(bad & (margin > TOL)), f"{int(np.sum(bad & (margin > TOL)))} integer lags differ"
+    if margin is not None and second is not None:
+        excused = bad & (margin <= TOL) & (li == second)
+        assert not np.any(bad & ~excused), f"{int(np.sum(bad & ~excused))} integer lags differ"
     else:
         assert not bad.any(), f"{int(bad.sum())} integer lags differ"
     ok = ~bad
@@ -77,7 +93,11 @@ def test_edge_cases_n256_fixture(xc, golden_dir):
     assert li[0, 0] == -(n - 1) and lf[0, 0] == 0.0 and pk[0, 0] == 0.0
     assert li[1, 0] == 20 and li[2, 0] == n - 1 and li[3, 0] == -(n - 1)
     assert lf[2, 0] == 0.0 and lf[3, 0] == 0.0
-    assert li[4, 0] in (-7, 9) and li[5, 0] == 0
+    # window 4: two impulses of equal height -> |r| has two maxima of 1.0 at lags -7 and +9 that are equal only up to
+    # the last bit of whichever FFT computed them (the fixture, i.e. pocketfft, records -7).  Which of two such
+    # values is larger is not part of the path's definition; the tie RULE (lowest 'full' index) is, and it is
+    # enforced where the kernel reproduces a tie exactly: test_exact_tie_resolves_to_lowest_index.
+    assert int(g["lag_int"][4, 0]) == -7 and li[4, 0] in (-7, 9) and li[5, 0] == 0
     assert np.allclose(pk[1:], g["peak"][1:], rtol=1e-5)
     # fractional lag of every window against the reference-generated values (windows 0, 2, 3: exactly 0
     # by the edge / flat-top rule; 1, 4: isolated impulses, the neighbour taps are round-off of a peak of
@@ -122,7 +142,7 @@ def test_edge_cases_n4096(xc):
     assert li[1, 0] == ri[1, 0] == 20
     assert li[2, 0] == ri[2, 0] == N - 1 and lf[2, 0] == 0.0
     assert li[3, 0] == ri[3, 0] == -(N - 1) and lf[3, 0] == 0.0
-    assert li[4, 0] in (-7, 9)              # exact tie up to FFT rounding: either candidate is a maximum
+    assert li[4, 0] in (-7, 9)              # a tie only up to each FFT's last bit (see test_edge_cases_n256_fixture)
     # constant inputs -> triangular |r|: the parabola's curvature is 2/N of its height, so one float32
     # ulp of tap asymmetry moves the vertex by eps32 * N/4 = 1.2e-4 samples.  The bar for such a
     # flat top is the 1e-5 of the spec OR 4 ulp of tap error through that conditioning.
@@ -307,9 +327,8 @@ def test_buoy_counts_n4096(xc, n_buoys, n_windows):
     with xc.XcorrEngine(n_buoys, 4096, n_windows) as eng:
         li, lf, pk = eng.correlate(iq)
     assert li.shape == (n_windows, n_buoys * (n_buoys - 1) // 2)
-    margin = np.array([[orc.peak_margin(iq[w, i], iq[w, j]) for (i, j) in orc.pair_list(n_buoys)]
-                       for w in range(n_windows)])
-    _assert_parity(li, lf, pk, ri, rf, rp, margin)
+    margin, second = _top2(iq[:n_windows], orc.pair_list(n_buoys))
+    _assert_parity(li, lf, pk, ri, rf, rp, margin, second)
     true = delays[:, orc.pair_list(n_buoys)[:, 1]] - delays[:, orc.pair_list(n_buoys)[:, 0]]
     assert np.all(np.abs(li + lf - true) < 0.5)
 
@@ -517,10 +536,10 @@ def test_every_path_by_window_length(xc, N):
     W = 3 if N <= 8192 else 1
     iq, delays = rm.synth.make_windows(W, 3, N, 2.4e6, seed=700 + N % 997)
     ri, rf, rp = orc.xcorr_batch_literal(iq)
-    margin = np.array([[orc.peak_margin(iq[w, i], iq[w, j]) for (i, j) in orc.pair_list(3)] for w in range(W)])
+    margin, second = _top2(iq[:W], orc.pair_list(3))
     with xc.XcorrEngine(3, N, W) as eng:
         li, lf, pk = eng.correlate(iq)
-    _assert_parity(li, lf, pk, ri, rf, rp, margin)
+    _assert_parity(li, lf, pk, ri, rf, rp, margin, second)
 
 
 def test_mixed_call_patterns_on_one_engine(xc):
@@ -609,13 +628,13 @@ def test_fused_row_kernel_by_row_length(xc, N, B, monkeypatch):
     W = 2
     iq, _ = rm.synth.make_windows(W, B, N, 2.4e6, seed=900 + B + N % 991)
     ri, rf, rp = orc.xcorr_batch_literal(iq)
-    margin = np.array([[orc.peak_margin(iq[w, i], iq[w, j]) for (i, j) in orc.pair_list(B)] for w in range(W)])
+    margin, second = _top2(iq[:W], orc.pair_list(B))
     custom = np.array([(B - 1, 0), (0, 1), (1, 1)], np.int32)      # reversed, plain, autocorrelation
     monkeypatch.setenv("RMX_FUSED", "2")       # (two windows would not fill the chip: the engine would pick the two-kernel passes)
     with xc.XcorrEngine(B, N, W) as eng:
         li, lf, pk = eng.correlate(iq)
         ci, cf, cp = eng.correlate(iq, custom)
-    _assert_parity(li, lf, pk, ri, rf, rp, margin)
+    _assert_parity(li, lf, pk, ri, rf, rp, margin, second)
     oi, of_, op = orc.xcorr_batch_literal(iq, custom)
     _assert_parity(ci, cf, cp, oi, of_, op)
     monkeypatch.setenv("RMX_FUSED", "0")
@@ -633,13 +652,13 @@ def test_whole_window_kernel_by_length(xc, N, B, monkeypatch):
     W = 19
     iq, _, raw = rm.synth.make_windows(W, B, N, 2.4e6, seed=700 + B + N % 977, return_u8=True)
     ri, rf, rp = orc.xcorr_batch_literal(iq)
-    margin = np.array([[orc.peak_margin(iq[w, i], iq[w, j]) for (i, j) in orc.pair_list(B)] for w in range(W)])
+    margin, second = _top2(iq[:W], orc.pair_list(B))
     custom = np.array([(B - 1, 0), (0, 1), (1, 1), (0, 1)], np.int32)
     with xc.XcorrEngine(B, N, W) as eng:
         li, lf, pk = eng.correlate(iq)
         l8, f8, p8 = eng.correlate(raw)
         ci, cf, cp = eng.correlate(iq, custom)
-    _assert_parity(li, lf, pk, ri, rf, rp, margin)
+    _assert_parity(li, lf, pk, ri, rf, rp, margin, second)
     assert np.array_equal(li, l8) and np.array_equal(lf, f8) and np.array_equal(pk, p8)
     oi, of_, op = orc.xcorr_batch_literal(iq, custom)
     _assert_parity(ci, cf, cp, oi, of_, op)
@@ -661,14 +680,14 @@ def test_whole_window_scratch_kernel_by_length(xc, N, B, monkeypatch):
     iq, _, raw = rm.synth.make_windows(W, B, N, 2.4e6, seed=800 + B + N % 977, return_u8=True)
     sub = slice(0, min(W, 12))                                   # literal oracle on the first windows, the rest by consistency
     ri, rf, rp = orc.xcorr_batch_literal(iq[sub])
-    margin = np.array([[orc.peak_margin(iq[w, i], iq[w, j]) for (i, j) in orc.pair_list(B)] for w in range(ri.shape[0])])
+    margin, second = _top2(iq[:ri.shape[0]], orc.pair_list(B))
     custom = np.array([(B - 1, 0), (0, 1), (1, 1), (0, 1)], np.int32)
     monkeypatch.setenv("RMX_WSCR", "2")        # (a few windows would not fill the chip: the engine would pick the per-transform kernels)
     with xc.XcorrEngine(B, N, W) as eng:
         li, lf, pk = eng.correlate(iq)
         l8, f8, p8 = eng.correlate(raw)
         ci, cf, cp = eng.correlate(iq[sub], custom)
-    _assert_parity(li[sub], lf[sub], pk[sub], ri, rf, rp, margin)
+    _assert_parity(li[sub], lf[sub], pk[sub], ri, rf, rp, margin, second)
     assert np.array_equal(li, l8) and np.array_equal(lf, f8) and np.array_equal(pk, p8)
     oi, of_, op = orc.xcorr_batch_literal(iq[sub], custom)
     _assert_parity(ci, cf, cp, oi, of_, op)
@@ -703,7 +722,7 @@ def test_seeded_random_shapes_and_pair_lists(xc, case):
         pairs = np.stack([a, b], axis=1).astype(np.int32)
     ri, rf, rp = orc.xcorr_batch_literal(iq, pairs)
     plist = orc.pair_list(B) if pairs is None else pairs
-    margin = np.array([[orc.peak_margin(iq[w, i], iq[w, j]) for (i, j) in plist] for w in range(W)])
+    margin, second = _top2(iq[:W], plist)
     with xc.XcorrEngine(B, N, W) as eng:
         li, lf, pk = eng.correlate(iq, pairs) if pairs is not None else eng.correlate(iq)
-    _assert_parity(li, lf, pk, ri, rf, rp, margin)
+    _assert_parity(li, lf, pk, ri, rf, rp, margin, second)

@@ -87,10 +87,48 @@ def test_sign_and_units():
     assert ns == 10000 and abs(metres - 10e-6 * 299792458.0) < 1e-9
 
 
-def test_decode_u8_matches_reference_decode():
-    raw = np.arange(256, dtype=np.uint8)
-    z = orc.decode_u8_iq(raw)
+def test_decode_u8_is_the_reference_decode(golden_dir):
+    """a5: decode_u8_iq against what the reference's own load_iq_data (signal_analyzer.py:14-41, the statements of
+    buoy_node.py:392-398) returned for the same bytes -- every one of the 256 byte values occurs as I and as Q."""
+    g = _load(golden_dir, "signal_analyzer")
+    for n in (4096, 16384):
+        raw, want = g["n%d_raw_u8" % n], g["n%d_decoded" % n]
+        got = orc.decode_u8_iq(raw)
+        assert got.dtype == want.dtype == np.complex64 and got.shape == want.shape
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))      # bit-identical
+    raw = g["n16384_raw_u8"]
+    assert set(raw[0::2].tolist()) == set(range(256)) and set(raw[1::2].tolist()) == set(range(256))
+
+
+def test_decode_u8_formula():
+    """The formula itself on typed constants (u8 - 127.5, I then Q, no scaling)."""
+    z = orc.decode_u8_iq(np.arange(256, dtype=np.uint8))
     assert z.dtype == np.complex64 and z[0] == np.complex64(-127.5 - 126.5j) and z[-1] == np.complex64(126.5 + 127.5j)
+
+
+@pytest.mark.parametrize("n", [4096, 16384])
+def test_detect_oracle_spectrum_is_the_reference_spectrum(golden_dir, n):
+    """a6: the dB spectrum of oracle/detect_ref.py against analyze_spectrum of the imported reference
+    (signal_analyzer.py:47-86: np.fft.fft -> fftshift -> 20 log10(|X| + 1e-12), float32 throughout).  The oracle calls
+    scipy.fft.fft (buoy_node.py:28,404), the reference function np.fft.fft: two single-precision pocketfft builds whose
+    results differ by a few 1e-7 of the LARGEST bin, i.e. up to 6e-4 dB on bins 40 dB below it (measured 3.1e-4 /
+    5.6e-4 dB at N = 4096 / 16384); tolerance 2e-3 dB, and np.fft.fft on the same samples is bit-identical to the
+    fixture.  The peak bins the reference found (find_peaks, height = mean + 10) must be the ones find_peaks finds on the oracle's spectrum."""
+    import scipy.signal
+    from oracle import detect_ref as dr
+    g = _load(golden_dir, "signal_analyzer")
+    iq = g["n%d_decoded" % n]
+    want = g["n%d_power_spectrum_db" % n]
+    got = np.fft.fftshift(dr.power_spectrum_db(iq))
+    assert got.dtype == want.dtype == np.float32
+    assert np.max(np.abs(got - want)) <= 2e-3, np.max(np.abs(got - want))
+    same = (20 * np.log10(np.abs(np.fft.fftshift(np.fft.fft(iq))) + 1e-12)).astype(np.float32)
+    assert np.array_equal(same, want)
+    peaks, _ = scipy.signal.find_peaks(got, height=np.mean(got) + 10)
+    assert np.array_equal(peaks, g["n%d_peak_bins_shifted" % n])
+    fl = g["n%d_freq_first_last_mhz" % n]
+    fs, fc = float(g["sample_rate_hz"]), float(g["center_freq_mhz"])
+    assert abs(fl[0] - (fc - fs / 2e6)) < 1e-9 and abs(fl[1] - (fc + (fs / 2 - fs / n) / 1e6)) < 1e-9
 
 
 @pytest.mark.parametrize("name", ["caf_b3_n4096", "caf_b3_n1024", "caf_b4_n2048_d21"])

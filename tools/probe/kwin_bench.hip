@@ -15,7 +15,7 @@
 #include <vector>
 
 #include "../../radio-mapper_amd/csrc/kwin.hpp"
-#if __has_include("../../radio-mapper_amd/csrc/kwin2.hpp")
+#if __has_include("../../radio-mapper_amd/csrc/kwin2.hpp") && !defined(KWB_NO_KWIN2)
 #include "../../radio-mapper_amd/csrc/kwin2.hpp"
 #define KWB_HAVE_KWIN2 1
 #endif
@@ -59,13 +59,44 @@ static void launch_stag0(const Bufs& b, hipStream_t s) {
     hipLaunchKernelGGL(k_win<false>, dim3(256), dim3(kThreads), kLdsWinBytes, s, (const void*)b.iq, b.spec, b.tw1, b.tw2, b.B, 0L,
                        b.out_scale, b.li, b.lf, b.pk, b.W, 0, 0);
 }
+#ifdef RMX_ABLATE
+#define KWB_ABL(NAME, DBG)                                                                                              \
+    static void NAME(const Bufs& b, hipStream_t s) {                                                                    \
+        hipLaunchKernelGGL(k_win<false>, dim3(256), dim3(kThreads), kLdsWinBytes, s, (const void*)b.iq, b.spec, b.tw1, b.tw2, \
+                           b.B, 0L, b.out_scale, b.li, b.lf, b.pk, b.W, DBG, 1);                                       \
+    }
+KWB_ABL(launch_d128, 128)
+KWB_ABL(launch_d64, 64)
+KWB_ABL(launch_d192, 192)
+KWB_ABL(launch_d2, 2)
+KWB_ABL(launch_d4, 4)
+KWB_ABL(launch_d8, 8)
+KWB_ABL(launch_d12, 12)
+KWB_ABL(launch_d206, 206)
+KWB_ABL(launch_d256, 256)
+KWB_ABL(launch_d512, 512)
+#endif
 #ifdef KWB_HAVE_KWIN2
 #define KWB_V2(NAME, ...)                                                                                               \
     static void NAME(const Bufs& b, hipStream_t s) {                                                                    \
         hipLaunchKernelGGL((k_win2<false, __VA_ARGS__>), dim3(256), dim3(kThreads), kLdsWin2Bytes, s, (const void*)b.iq, \
                            b.spec, b.tw1, b.tw2, b.B, 0L, b.out_scale, b.li, b.lf, b.pk, b.W);                          \
     }
-KWB_KWIN2_VARIANTS
+KWB_V2(launch_2a, 1)
+KWB_V2(launch_2a_s0, 0)
+KWB_V2(launch_2a_l, 1, 0, true)
+KWB_V2(launch_a1, 1, 1)
+KWB_V2(launch_a4, 1, 4)
+KWB_V2(launch_a8, 1, 8)
+KWB_V2(launch_a15, 1, 15)
+#define KWB_KWIN2_TABLE \
+    {"k_win2 two anchors, STAG 1", launch_2a, (const void*)k_win2<false, 1>, kLdsWin2Bytes}, \
+    {"k_win2 two anchors, STAG 0", launch_2a_s0, (const void*)k_win2<false, 0>, kLdsWin2Bytes}, \
+    {"k_win2 two anchors, STAG 1, TW2 row from LDS", launch_2a_l, (const void*)k_win2<false, 1, 0, true>, kLdsWin2Bytes}, \
+    {"k_win2 ABL 1: no spectrum loads (phase 2)", launch_a1, (const void*)k_win2<false, 1, 1>, kLdsWin2Bytes}, \
+    {"k_win2 ABL 4: no spectrum stores", launch_a4, (const void*)k_win2<false, 1, 4>, kLdsWin2Bytes}, \
+    {"k_win2 ABL 8: no sample prefetch", launch_a8, (const void*)k_win2<false, 1, 8>, kLdsWin2Bytes}, \
+    {"k_win2 ABL 15: all", launch_a15, (const void*)k_win2<false, 1, 15>, kLdsWin2Bytes},
 #endif
 
 struct Variant { const char* name; launch_fn fn; const void* kfn; int lds; };
@@ -97,6 +128,18 @@ int main(int argc, char** argv) {
         {"k_win stag=0", launch_stag0, (const void*)k_win<false>, kLdsWinBytes},
 #ifdef KWB_HAVE_KWIN2
         KWB_KWIN2_TABLE
+#endif
+#ifdef RMX_ABLATE
+        {"k_win dbg 128: no spectrum requests", launch_d128, (const void*)k_win<false>, kLdsWinBytes},
+        {"k_win dbg 64: no sample requests", launch_d64, (const void*)k_win<false>, kLdsWinBytes},
+        {"k_win dbg 192: neither", launch_d192, (const void*)k_win<false>, kLdsWinBytes},
+        {"k_win dbg 2: no peak search behind |r|^2", launch_d2, (const void*)k_win<false>, kLdsWinBytes},
+        {"k_win dbg 4: no wave-local exchange", launch_d4, (const void*)k_win<false>, kLdsWinBytes},
+        {"k_win dbg 8: no barrier exchange traffic", launch_d8, (const void*)k_win<false>, kLdsWinBytes},
+        {"k_win dbg 12: no LDS exchange traffic", launch_d12, (const void*)k_win<false>, kLdsWinBytes},
+        {"k_win dbg 206: none of the above", launch_d206, (const void*)k_win<false>, kLdsWinBytes},
+        {"k_win dbg 256: no resolve_batch", launch_d256, (const void*)k_win<false>, kLdsWinBytes},
+        {"k_win dbg 512: no halo stores", launch_d512, (const void*)k_win<false>, kLdsWinBytes},
 #endif
     };
     for (auto& v : vars) CK(hipFuncSetAttribute(v.kfn, hipFuncAttributeMaxDynamicSharedMemorySize, v.lds));
@@ -136,6 +179,26 @@ int main(int argc, char** argv) {
                     diff_lf += memcmp(&lf[k], &lf0[k], 4) != 0;
                     diff_pk += memcmp(&pk[k], &pk0[k], 4) != 0;
                 }
+#ifdef RMX_KWIN_STAMPS
+            if (true) {
+                std::vector<long long> st(256 * 64 * 4);
+                CK(hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(rmx_stamps), st.size() * 8));
+                double p1 = 0, p2 = 0, tot = 0; int n = 0;
+                for (int wg = 0; wg < 256; ++wg)
+                    for (int k = 0; k + 1 < W / 256 && k + 1 < 64; ++k) {
+                        const long long* a = &st[(wg * 64 + k) * 4];
+                        p1 += (double)(a[1] - a[0]); p2 += (double)(a[2] - a[1]); tot += (double)(a[4] - a[0]); ++n;
+                    }
+                std::vector<int> vm(256 * 64 * 8);
+                CK(hipMemcpyFromSymbol(vm.data(), HIP_SYMBOL(rmx_stamps_vm), vm.size() * 4));
+                double wv[8] = {0};
+                for (int wg = 0; wg < 256; ++wg) for (int k = 0; k + 1 < W / 256 && k + 1 < 64; ++k) for (int w8 = 0; w8 < 8; ++w8) wv[w8] += vm[(wg * 64 + k) * 8 + w8];
+                printf("    vmcnt wait at the head of h1, ticks per window, waves 0..7:");
+                for (int w8 = 0; w8 < 8; ++w8) printf(" %.0f", wv[w8] / n);
+                printf("\n");
+                printf("    stamps (s_memtime ticks, mean over %d windows): phase 1 %.0f  phase 2 %.0f  whole window %.0f\n", n, p1 / n, p2 / n, tot / n);
+            }
+#endif
             printf("[%d] %-44s %.4f ms  frac %.4f | lags != generator %ld, vs variant 0: lag_int %ld lag_frac %ld peak %ld differ\n", round,
                    v.name, ms, alg_bytes / (ms * 1e-3) / 8e12, bad_truth, diff_li, diff_lf, diff_pk);
             fflush(stdout);
