@@ -231,7 +231,9 @@ def main():
     # rehearsal knobs for a one-GPU box (never set by the driver): RMX_BENCH_SAME_DEVICE=1 runs all
     # ranks on cuda:0 (with the gloo backend: RCCL refuses two ranks on one device)
     same_dev = os.environ.get("RMX_BENCH_SAME_DEVICE") == "1"
-    backend = os.environ.get("RMX_BENCH_BACKEND", "gloo" if (same_dev or args.launch_check and not torch.cuda.is_available()) else "nccl")
+    # --launch-check never initialises a device (it is documented, and tested, as needing no GPU: on a box with fewer
+    # GPUs than ranks the nccl branch would set_device() a card that does not exist)
+    backend = os.environ.get("RMX_BENCH_BACKEND", "gloo" if (same_dev or args.launch_check) else "nccl")
     dev_index = 0 if same_dev else local_rank
     dist = None
     if world > 1:

@@ -21,8 +21,8 @@ Same public names, argument meaning and error behaviour as the reference module 
 Without IQ on the detections every number equals the reference's (pinned by
 tests/golden/tdoa_conventions.json).  With IQ the lag comes from ``xcorr.XcorrEngine`` (HIP, gfx950);
 there is no CPU fallback and no silent degradation to timestamps: if IQ is supplied and the HIP library
-or a GPU is missing, the seam logs the engine's error on ``...TDoACalculator`` and yields no
-measurements (the reference's log-and-return convention, tdoa_processor.py:151-153);
+or a GPU is missing -- or only some detections of a group carry IQ, or their windows differ in length, dtype or
+sample rate -- the seam logs the error on ``...TDoACalculator`` and yields no measurements for that group (the reference's log-and-return convention, tdoa_processor.py:151-153);
 ``TDoACalculator.measure_lags`` itself raises (ImportError / RmxError).
 """
 from __future__ import annotations
@@ -141,9 +141,13 @@ class TDoACalculator:
     SPEED_OF_LIGHT = _C  # tdoa_processor.py:141
     MAX_ENGINES = 4      # engines kept alive (one rmx_ctx each: device scratch), least recently used evicted
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, devices: Optional[Sequence[int]] = None):
+        """device: the GPU of a single-device calculator (the default).  devices: a list of GPUs, or "all" for every
+        visible one -- with more than one entry a batch of windows / frequency groups is block-sharded over them by
+        `multi.MultiXcorrEngine` (one rmx_ctx and one host thread per device, no collective)."""
         self.logger = logging.getLogger(__name__ + ".TDoACalculator")
         self.device = device
+        self.devices = devices
         self._engines: Dict[Tuple[int, int], Any] = {}   # insertion order = recency
 
     # -- GPU engine cache ------------------------------------------------------------------------
@@ -154,7 +158,17 @@ class TDoACalculator:
         if eng is None or eng.max_windows < n_windows:
             if eng is not None:
                 eng.close()
-            eng = xcorr.XcorrEngine(n_buoys, n_samples, max(n_windows, 1), device=self.device)
+            devs = self.devices
+            if isinstance(devs, str):
+                if devs != "all":
+                    raise ValueError('devices must be a list of device indices or "all"')
+                devs = list(range(xcorr.device_count()))
+            if devs is not None and len(devs) > 1:
+                from . import multi
+                eng = multi.MultiXcorrEngine(n_buoys, n_samples, max(n_windows, 1), devices=devs)
+            else:
+                eng = xcorr.XcorrEngine(n_buoys, n_samples, max(n_windows, 1),
+                                        device=self.device if not devs else int(devs[0]))
         self._engines[key] = eng                         # most recently used last
         while len(self._engines) > self.MAX_ENGINES:
             old = next(iter(self._engines))
@@ -200,14 +214,16 @@ class TDoACalculator:
         iqs = [self._iq_of(d) for d in detections]
         if all(a is None for a in iqs):
             return None, None
+        # IQ was supplied for this group: from here on the time tags alone are never used for it.  A group that
+        # cannot be correlated as one [B][N] batch yields no measurements (logged), as an engine failure does.
         if any(a is None for a in iqs):
-            self.logger.warning("Only some detections carry IQ windows; using time tags only")
-            return None, None
+            self.logger.error("Only some detections of the group carry IQ windows; no TDoA measurements for it")
+            return False, None
         shapes = {(a.dtype.str, a.shape) for a in iqs}
         rates = {float(d.sample_rate_hz) for d in detections}
         if len(shapes) != 1 or len(rates) != 1:
-            self.logger.warning("IQ windows differ in length/dtype/sample rate; using time tags only")
-            return None, None
+            self.logger.error("IQ windows of the group differ in length/dtype/sample rate; no TDoA measurements for it")
+            return False, None
         dt, shp = next(iter(shapes))
         return (len(iqs), dt, shp, next(iter(rates))), np.stack(iqs)
 
@@ -217,8 +233,14 @@ class TDoACalculator:
         try:
             li, lf, _ = self.measure_lags(stacked)
             return li.astype(np.float64) + lf.astype(np.float64)
-        except Exception as e:   # RmxError (no device, bad shape), ImportError (library not built), ...
+        except (ImportError, OSError) as e:   # library not built / not loadable
             self.logger.error(f"Cross-correlation engine failed: {e}")
+            return None
+        except Exception as e:
+            from . import xcorr
+            if not isinstance(e, xcorr.RmxError):    # programming errors (shapes, types) surface
+                raise
+            self.logger.error(f"Cross-correlation engine failed: {e}")   # no device, engine refused the batch
             return None
 
     def _timing_confidence(self, b1: BuoyPosition, b2: BuoyPosition) -> float:
@@ -227,14 +249,15 @@ class TDoACalculator:
 
     _calculate_timing_confidence = _timing_confidence  # reference's private name
 
-    _NO_LAG = object()
+    _NO_LAG = object()      # calculate_tdoa_measurements inspects the detections itself
+    _TIME_TAGS = object()   # the caller already did and found no IQ: the reference's arithmetic (:166)
 
     def calculate_tdoa_measurements(self, detections: List[SignalDetection],
                                     buoy_positions: Dict[str, BuoyPosition],
                                     _lag=_NO_LAG) -> List[TDoAMeasurement]:
-        """The reference's pair loop (tdoa_processor.py:146-198).  `_lag` (private): this group's
-        [P] lags already measured in a batch with other groups by TDoAProcessor, or None when that batch
-        failed."""
+        """The reference's pair loop (tdoa_processor.py:146-198).  `_lag` (private): (lags [P], sample rate) of this
+        group, already measured in a batch with other groups by TDoAProcessor; None when that batch failed or the
+        group's IQ could not be batched; `_TIME_TAGS` when TDoAProcessor found no IQ on the group."""
         out: List[TDoAMeasurement] = []
         nd = len(detections)
         if nd < 2:
@@ -244,6 +267,8 @@ class TDoACalculator:
         fs = None
         if _lag is self._NO_LAG:
             key, stacked = self._iq_batch_key(detections)
+            if key is False:
+                return out
             if key:
                 res = self._measure_groups(stacked[None])
                 if res is None:
@@ -251,8 +276,8 @@ class TDoACalculator:
                 lag, fs = res[0], key[3]
         elif _lag is None:
             return out
-        else:
-            lag, fs = _lag, float(detections[0].sample_rate_hz)
+        elif _lag is not self._TIME_TAGS:
+            lag, fs = _lag
         q = -1
         for i in range(nd):
             for j in range(i + 1, nd):
@@ -400,8 +425,8 @@ class TDoAProcessor:
                 self.logger.debug(f"Insufficient detections for {freq} MHz ({len(recent)} < "
                                   f"{self.min_buoys_for_triangulation})")
                 continue
-            key, stacked = self.tdoa_calculator._iq_batch_key(recent)
-            work.append([freq, recent, key, stacked, TDoACalculator._NO_LAG])
+            key, stacked = self.tdoa_calculator._iq_batch_key(recent)   # inspected (and logged) once per group
+            work.append([freq, recent, key, stacked, TDoACalculator._TIME_TAGS if key is None else None])
         batches: Dict[Any, List[int]] = {}
         for n, item in enumerate(work):
             if item[2]:
@@ -409,13 +434,10 @@ class TDoAProcessor:
         for key, members in batches.items():
             lags = self.tdoa_calculator._measure_groups(np.stack([work[n][3] for n in members]))
             for k, n in enumerate(members):
-                work[n][4] = None if lags is None else lags[k]
+                work[n][4] = None if lags is None else (lags[k], key[3])
         results: List[TriangulationResult] = []
         for freq, recent, key, _, lag in work:
-            if key:
-                meas = self.tdoa_calculator.calculate_tdoa_measurements(recent, self.buoy_positions, _lag=lag)
-            else:
-                meas = self.tdoa_calculator.calculate_tdoa_measurements(recent, self.buoy_positions)
+            meas = self.tdoa_calculator.calculate_tdoa_measurements(recent, self.buoy_positions, _lag=lag)
             if len(meas) < 2:
                 self.logger.debug(f"Insufficient TDoA measurements for {freq} MHz")
                 continue

@@ -149,6 +149,40 @@ def test_engine_failure_is_logged_not_raised(conv, caplog):
         p.tdoa_calculator.measure_lags(np.stack([d.iq_samples for d in dets])[None])   # the engine entry itself raises
 
 
+def test_partial_or_mismatched_iq_yields_no_measurements(conv, monkeypatch, caplog):
+    """Once any detection of a group carries IQ the time tags alone are never used for that group: a group in which
+    only some detections carry IQ, or whose windows differ in length or sample rate, is logged on ...TDoACalculator
+    and yields no measurements (the log-and-return convention of tdoa_processor.py:151-153); the engine is not called,
+    the message is logged once per group, and a group WITHOUT any IQ in the same call still gets the reference's
+    timestamp arithmetic (:166)."""
+    p = _proc(conv)
+    called = []
+    monkeypatch.setattr(p.tdoa_calculator, "measure_lags", lambda iq, pairs=None: called.append(1))
+    dets = _iq_dets(conv, 121.5, seed=4)
+    dets[1].iq_samples = None                                        # only some carry IQ
+    other = _iq_dets(conv, 156.8, seed=5)
+    other[2].iq_samples = other[2].iq_samples[:32]                   # lengths differ
+    third = _iq_dets(conv, 243.0, seed=6)
+    third[0].sample_rate_hz = 1.0e6                                  # sample rates differ
+    plain = [tp.SignalDetection(d.buoy_id, 406.0, -50, "t", d.gps_timestamp_ns, d.lat, d.lng, 0.9) for d in dets]
+    with caplog.at_level("ERROR"):
+        for group in (dets, other, third):
+            assert p.tdoa_calculator.calculate_tdoa_measurements(group, p.buoy_positions) == []
+    assert not called
+    msgs = [r.message for r in caplog.records if r.name.endswith("TDoACalculator")]
+    assert len(msgs) == 3 and "Only some detections" in msgs[0] and "differ" in msgs[1] and "differ" in msgs[2]
+    caplog.clear()
+    seen = {}
+    orig = p.hyperbolic_positioner.triangulate_position
+    monkeypatch.setattr(p.hyperbolic_positioner, "triangulate_position",
+                        lambda meas, pos: seen.setdefault(meas[0].frequency_mhz, [m.time_difference_ns for m in meas]) and orig(meas, pos))
+    with caplog.at_level("ERROR"):
+        p.process_signal_detections(dets + other + plain)
+    assert not called and list(seen) == [406.0]                      # only the group without IQ is measured ...
+    assert seen[406.0] == [1000, 2000, 1000]                         # ... from its time tags alone
+    assert len([r for r in caplog.records if r.name.endswith("TDoACalculator")]) == 2   # one line per bad group
+
+
 def test_measure_lags_channel_axis_and_engine_cache(monkeypatch):
     calc = tp.TDoACalculator()
     made = []
