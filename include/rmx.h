@@ -82,16 +82,26 @@ const char* rmx_last_error(const rmx_ctx* ctx);
 /* Use an existing hipStream_t (e.g. torch's current stream) for all work of this ctx. */
 int rmx_set_stream(rmx_ctx* ctx, void* hip_stream);
 
-/* Tuning knobs (all optional): "chunk_windows" (windows per launch), "timing" (1: bracket every
+/* Per-ctx options (all optional): "chunk_windows" (windows per launch), "timing" (1: bracket every
  * launch with HIP events, read back with rmx_last_timing), "fused" (default 1; 0 forces the separate
  * forward + pair kernels that custom pair lists use), "resident" and "pairs_per_block" (variants of
- * that unfused pair kernel), "win8" / "pk" (1: run the fused N = 4096 path on k_win8 -- 8 points x 1024
- * threads, 4 waves per SIMD -- or on k_winp -- k_win on packed fp32 -- instead of k_win; same results to
- * rounding, measured slower: DESIGN.md section 6), "stag" (0..4, k_win8's half-order staggering),
- * "dbg" (ablation masks of the -DRMX_ABLATE timing build; every other build
- * rejects the key with RMX_E_UNSUPPORTED and compiles the masks out of all kernels).
+ * that unfused pair kernel), "stag" (0..5: which waves of the fused N = 4096 kernel run the two halves
+ * between barriers in the opposite order; default 1), "win8" / "pk" (the two other builds of that kernel,
+ * present only in a -DRMX_EXPERIMENTS build, RMX_E_UNSUPPORTED otherwise), "dbg"
+ * (ablation masks of the -DRMX_ABLATE timing build; every other build rejects the key with
+ * RMX_E_UNSUPPORTED and compiles the masks out of all kernels).
  * Returns RMX_E_INVAL for an unknown key. */
 int rmx_set_option(rmx_ctx* ctx, const char* key, long value);
+
+/* Kernel-selection defaults for engines created AFTERWARDS (process-wide; an existing ctx keeps the values it was
+ * created with, so its kernels, block sizes and LDS sizes stay consistent).  For tests and A/B measurements: the
+ * library never reads the environment.  Keys (radio-mapper_amd/csrc/host_plan.hpp lists ranges and meanings):
+ * "stag", "ncus", "chunk_windows", "generic4096", "small_maxl", "logl1", "wfused", "wscr", "wscr14",
+ * "wscr_per_cu", "rows_anchor", "fused", "fused_def", "gen_chunk", "rows_tpr", "cols_threads", "col_logt".
+ * Returns RMX_E_INVAL (text through rmx_last_error(NULL)) for an unknown key or a value out of range;
+ * value == LONG_MIN removes a key; rmx_clear_default_options() removes all. */
+int rmx_set_default_option(const char* key, long value);
+void rmx_clear_default_options(void);
 
 /* The hot path.
  *   iq        complex64 interleaved I,Q  [n_windows][n_buoys][n_samples][2] float32, row-major

@@ -359,6 +359,92 @@ __device__ __forceinline__ void xchg_bc_read_b(const float2* lds, float2 (&v)[16
         for (int q1 = 0; q1 < 4; ++q1) v[q0 + 4 * q1] = base[(q0 + 4 * q1) * kBcRow];
 }
 
+// ---- second generation of the exchanges (k_win only; the kernels of the unfused path keep the ones above) -------------
+// Measured (tools/probe/lds_forms.hip): a store's cost is the transfer of its address and data VGPRs to the LDS --
+// ds_write_b64 6 cycles per 512 B, ds_write_addtid_b32 (no address VGPR: address = M0 + offset + 4*lane) 2 cycles per
+// 256 B -- and the wave-local exchange, whose reads wait for the wave's own stores, is where that shows (-8.5 % of a
+// three-pass transform loop when only it changes).  So the B<->C exchange becomes PLANAR (re plane, im plane) in a
+// per-wave region: the writer stores slot s of every lane with two ds_write_addtid_b32 into row s (64 consecutive
+// floats), the reader fetches its 16 inputs -- 16 consecutive floats of ONE row, written by the 16 lanes that share
+// its upper bits -- with 2 x 4 ds_read_b128.  That needs the exchanged digit in lane bits 0-3 on the writing side:
+//     role B   lane = n0 | p << 4 | (k0 & 1) << 5,  wave = k0 >> 1        (t = n0 | p << 4 | k0 << 5)
+//     role C   lane = k1 | (k0 & 1) << 4 | p << 5,  wave = k0 >> 1
+// (role A keeps t = 2 (16 n1 + n0) + p: sample loads, last radix-2 by DPP and the peak search are untouched).
+// Rows are 272 bytes apart and the rows of slots {0-3, 12-15} sit on even positions, the others on odd ones: a
+// ds_read_b128 serves lanes {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... together, and with the reader's 16-lane
+// source group taken as 2 * bit4 + bit5 of its lane every such set of 16 lanes hits 16 different bank quads (brute
+// force over all layouts: tools/model_kwin_lds.py).  Reader and writer of a direction differ exactly by that swap
+// of bits 4 and 5, which is why ONE lane map per role serves both directions.
+// The barrier image becomes [k0][n1][p][n0] (complex): role B reads / writes 16 consecutive complex per 16-lane
+// group and (n0, p) = 32 consecutive per half wave; role A reads conflict free (its lane pairs sit 128 bytes
+// apart); only role A's stores of the FORWARD transform are 2-way conflicted (8 of 36 transforms).
+constexpr int kLocRow = 272;                   // bytes between rows of the wave-local planar image
+constexpr int kLocPlane = 16 * kLocRow;        // re plane, then im plane
+constexpr int kLocWave = 2 * kLocPlane;        // 8704 bytes per wave = the wave's two k0 rows of the barrier image
+static_assert(kLocWave == 2 * kBcHalf * 8, "the wave-local region is the wave's own part of the exchange image");
+__host__ __device__ constexpr int loc_pos(int s) { return s < 4 ? 2 * s : (s >= 12 ? 2 * (s - 8) : 2 * (s - 4) + 1); }
+
+// eight floats = four complex slots S0..S3 of every lane into their rows (M0 = byte address of the wave's region)
+template <int S0, int S1, int S2, int S3>
+__device__ __forceinline__ void loc_write4(int m0, const float2& a, const float2& b, const float2& c, const float2& d) {
+    asm volatile(
+        "s_mov_b32 m0, %8\n\ts_nop 0\n\t"
+        "ds_write_addtid_b32 %0 offset:%9\n\tds_write_addtid_b32 %1 offset:%10\n\t"
+        "ds_write_addtid_b32 %2 offset:%11\n\tds_write_addtid_b32 %3 offset:%12\n\t"
+        "ds_write_addtid_b32 %4 offset:%13\n\tds_write_addtid_b32 %5 offset:%14\n\t"
+        "ds_write_addtid_b32 %6 offset:%15\n\tds_write_addtid_b32 %7 offset:%16"
+        ::"v"(a.x), "v"(a.y), "v"(b.x), "v"(b.y), "v"(c.x), "v"(c.y), "v"(d.x), "v"(d.y), "s"(m0),
+          "n"(loc_pos(S0) * kLocRow), "n"(kLocPlane + loc_pos(S0) * kLocRow), "n"(loc_pos(S1) * kLocRow),
+          "n"(kLocPlane + loc_pos(S1) * kLocRow), "n"(loc_pos(S2) * kLocRow), "n"(kLocPlane + loc_pos(S2) * kLocRow),
+          "n"(loc_pos(S3) * kLocRow), "n"(kLocPlane + loc_pos(S3) * kLocRow)
+        : "memory");
+}
+__device__ __forceinline__ void loc_write16(int m0, const float2 (&v)[16]) {
+    loc_write4<0, 1, 2, 3>(m0, v[0], v[1], v[2], v[3]);
+    loc_write4<4, 5, 6, 7>(m0, v[4], v[5], v[6], v[7]);
+    loc_write4<8, 9, 10, 11>(m0, v[8], v[9], v[10], v[11]);
+    loc_write4<12, 13, 14, 15>(m0, v[12], v[13], v[14], v[15]);
+}
+// byte offset, inside the wave's region, of the 16 floats this lane reads (re plane; im plane + kLocPlane)
+__device__ __forceinline__ int loc_read_off(int lane) {
+    const int d = lane & 15;
+    const int pos = d < 4 ? 2 * d : (d >= 12 ? 2 * (d - 8) : 2 * (d - 4) + 1);
+    return pos * kLocRow + (((lane >> 4) & 1) * 2 + (lane >> 5)) * 64;
+}
+// the 16 inputs of this lane: slot q = float q of its run (rd = region + loc_read_off(lane))
+__device__ __forceinline__ void loc_read16(const char* rd, float2 (&v)[16]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float4 re = *reinterpret_cast<const float4*>(rd + 16 * j);
+        const float4 im = *reinterpret_cast<const float4*>(rd + kLocPlane + 16 * j);
+        v[4 * j] = make_float2(re.x, im.x);
+        v[4 * j + 1] = make_float2(re.y, im.y);
+        v[4 * j + 2] = make_float2(re.z, im.z);
+        v[4 * j + 3] = make_float2(re.w, im.w);
+    }
+}
+// barrier image [k0][n1][p][n0]: complex index of (k0 = 0, n1 = 0) for this thread in role A / role B; slot k0
+// (role A) adds k0 * kBcHalf, slot n1 (role B) adds 32 * n1
+__device__ __forceinline__ int xa2_base(int t) { const int p = t & 1, u = t >> 1; return 32 * (u >> 4) + 16 * p + (u & 15); }
+__device__ __forceinline__ int xb2_base(int t) { return (t >> 5) * kBcHalf + 16 * ((t >> 4) & 1) + (t & 15); }
+__device__ __forceinline__ void xchg_a2_write(float2* lds, const float2 (&v)[16], int t) {
+    float2* b = lds + xa2_base(t);
+#pragma unroll
+    for (int k0 = 0; k0 < 16; ++k0) b[k0 * kBcHalf] = make_float2(v[k0].x, v[k0].y);
+}
+__device__ __forceinline__ void xchg_a2_read(const float2* lds, float2 (&v)[16], int t) {
+    const float2* b = lds + xa2_base(t);
+#pragma unroll
+    for (int q0 = 0; q0 < 4; ++q0)
+#pragma unroll
+        for (int q1 = 0; q1 < 4; ++q1) v[q0 + 4 * q1] = b[(q0 + 4 * q1) * kBcHalf];
+}
+__device__ __forceinline__ void xchg_b2_read(const float2* lds, float2 (&v)[16], int t) {
+    const float2* b = lds + xb2_base(t);
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) v[n1] = b[n1 * 32];
+}
+
 // TW2[a][b] = W_256^(a*b) lives in LDS as 16 rows of 16 complex padded to 18 (144-B rows: the 16
 // rows then start on 16 distinct 16-B bank groups, so a ds_read_b128 of one column is conflict free).
 constexpr int kTw2RowF2 = 18;

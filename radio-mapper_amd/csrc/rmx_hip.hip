@@ -24,19 +24,17 @@
 #include <vector>
 
 #include "../../include/rmx.h"
+#include "host_plan.hpp"
 #include "fft_r16.hpp"
 #include "kwin.hpp"
-#include "win8.hpp"
-#include "winpk.hpp"
+#include "win8.hpp"    // (radix-8 register blocks shared with generic_path.hpp; its kernel k_win8 is instantiated only under
+#include "winpk.hpp"   //  -DRMX_EXPERIMENTS, like k_winp: templates that nothing references cost nothing)
 #include "generic_path.hpp"
 #include "detect_path.hpp"
 
 namespace rmx {
 
 
-struct PairItem {
-    int i, j, out, run;   // run: items left in this anchor run (same i), this one included
-};
 
 
 // ------------------------------------------------------------------------------------------------
@@ -452,6 +450,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_pair_res(
 }
 
 
+#ifdef RMX_EXPERIMENTS
 // k_win on packed fp32 (winpk.hpp): same protocol, same resolve routine
 template <bool U8>
 __global__ __launch_bounds__(kThreads, 2) void k_winp(const void* __restrict__ iq_v, float4* __restrict__ spec,
@@ -465,6 +464,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_winp(const void* __restrict__ i
                           resolve_batch(lane, red, halo, oidx, first, cnt, obase, osc, li, lf, pk_);
                       });
 }
+#endif
 
 #define RMX_PAIR_ARGS                                                                                         \
     const float4 *__restrict__ spec, const float4 *__restrict__ spec_j, const float4 *__restrict__ tw1_g,     \
@@ -602,6 +602,7 @@ static thread_local std::string g_create_error;
 }  // namespace rmx
 
 struct rmx_ctx {
+    rmx::host::Knobs knobs;   // kernel-selection options as they were at rmx_create (host_plan.hpp)
     int device = 0;
     int n_cus = 256;   // compute units of the device (persistent-grid size of the fused kernel)
     int n_buoys = 0, n_samples = 0, max_windows = 0;
@@ -631,6 +632,7 @@ struct rmx_ctx {
     // generic path (n_samples != 4096): see generic_path.hpp
     bool generic = false;
     int g_logL = 0, g_logL1 = 0, g_logL2 = 0, g_lo_bits = 0, g_chunk = 0;
+    size_t g_dyn_bytes = 0, g_pair_bytes = 0;   // chunk-sized buffers of generic_ensure (all of them / the pair-dependent ones)
     bool g_fused = false;      // four-step: both row passes in g_rows_fused (n_buoys <= 4, plain batches)
     bool g_fused_always = false;
     const void* g_fused_fn = nullptr;
@@ -707,9 +709,10 @@ static int fail(rmx_ctx* c, int code, const char* fmt, ...) {
                         __FILE__, __LINE__);                                                      \
     } while (0)
 
-static bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
+using host::is_pow2;
 
 
+#ifdef RMX_EXPERIMENTS
 // tables of k_win8 (win8.hpp; the same values tools/model_win8.py checks against numpy's FFT)
 static void build_tables8(std::vector<float4>& tw1, std::vector<float2>& tb, std::vector<float2>& tc) {
     const double two_pi = 6.283185307179586476925286766559;
@@ -737,6 +740,7 @@ static void build_tables8(std::vector<float4>& tw1, std::vector<float2>& tb, std
     fill(tb, 64, 512);   // W_512^(c1 * lane), lane = n0 + 8 n1
     fill(tc, 8, 64);     // W_64^(d0 * n0)
 }
+#endif
 
 static int ensure_events(rmx_ctx* c, size_t n) {
     while (c->ev.size() < n) {
@@ -747,46 +751,22 @@ static int ensure_events(rmx_ctx* c, size_t n) {
     return RMX_OK;
 }
 
-// pair plan: items sorted as given, cut into parts of <= pairs_per_block consecutive items
+// pair plan (host_plan.hpp: validation, anchor runs, parts of <= pairs_per_block consecutive items) -> device copies
 static int build_plan(rmx_ctx* c, const int32_t* pairs, int n_pairs) {
-    std::vector<int32_t> pl;
-    if (pairs) {
-        pl.assign(pairs, pairs + 2 * (size_t)n_pairs);
-    } else {
-        for (int i = 0; i < c->n_buoys; ++i)
-            for (int j = i + 1; j < c->n_buoys; ++j) { pl.push_back(i); pl.push_back(j); }
-    }
-    if (c->plan_n_pairs == n_pairs && c->plan_ppb == c->pairs_per_block && pl == c->plan_pairs) return RMX_OK;
-    for (int q = 0; q < n_pairs; ++q) {
-        const int i = pl[2 * q], j = pl[2 * q + 1];
-        if (i < 0 || j < 0 || i >= c->n_buoys || j >= c->n_buoys)
-            return fail(c, RMX_E_INVAL, "pair %d = (%d,%d) out of range for %d buoys", q, i, j, c->n_buoys);
-    }
-    std::vector<PairItem> items(n_pairs);
-    for (int q = 0; q < n_pairs; ++q) items[q] = PairItem{pl[2 * q], pl[2 * q + 1], q, 1};
-    for (int q = n_pairs - 2; q >= 0; --q)
-        if (items[q].i == items[q + 1].i) items[q].run = items[q + 1].run + 1;
-    const int ppb = c->pairs_per_block > 0 ? c->pairs_per_block : 7;
-    const int n_parts = (n_pairs + ppb - 1) / ppb;
-    std::vector<int> pb(n_parts + 1);
-    for (int k = 0; k <= n_parts; ++k) pb[k] = (int)((long)k * n_pairs / n_parts);
+    host::PairPlan pp;
+    std::string why;
+    if (host::make_pair_plan(c->n_buoys, pairs, n_pairs, c->pairs_per_block, &pp, &why) != 0) return fail(c, RMX_E_INVAL, "%s", why.c_str());
+    if (c->plan_n_pairs == n_pairs && c->plan_ppb == c->pairs_per_block && pp.pairs == c->plan_pairs) return RMX_OK;
     if (c->d_items) { (void)hipFree(c->d_items); c->d_items = nullptr; }
     if (c->d_part_begin) { (void)hipFree(c->d_part_begin); c->d_part_begin = nullptr; }
     RMX_HIP(c, hipMalloc((void**)&c->d_items, sizeof(PairItem) * (size_t)n_pairs));
-    RMX_HIP(c, hipMalloc((void**)&c->d_part_begin, sizeof(int) * (size_t)(n_parts + 1)));
-    RMX_HIP(c, hipMemcpy(c->d_items, items.data(), sizeof(PairItem) * (size_t)n_pairs, hipMemcpyHostToDevice));
-    RMX_HIP(c, hipMemcpy(c->d_part_begin, pb.data(), sizeof(int) * (size_t)(n_parts + 1), hipMemcpyHostToDevice));
-    {
-        bool all = n_pairs == c->n_buoys * (c->n_buoys - 1) / 2;
-        int q = 0;
-        for (int i = 0; all && i < c->n_buoys; ++i)
-            for (int j = i + 1; j < c->n_buoys; ++j, ++q)
-                if (pl[2 * q] != i || pl[2 * q + 1] != j) { all = false; break; }
-        c->plan_all_pairs = all;
-    }
-    c->plan_pairs.swap(pl);
+    RMX_HIP(c, hipMalloc((void**)&c->d_part_begin, sizeof(int) * (size_t)(pp.n_parts + 1)));
+    RMX_HIP(c, hipMemcpy(c->d_items, pp.items.data(), sizeof(PairItem) * (size_t)n_pairs, hipMemcpyHostToDevice));
+    RMX_HIP(c, hipMemcpy(c->d_part_begin, pp.part_begin.data(), sizeof(int) * (size_t)(pp.n_parts + 1), hipMemcpyHostToDevice));
+    c->plan_all_pairs = pp.all_pairs;
+    c->plan_pairs.swap(pp.pairs);
     c->plan_n_pairs = n_pairs;
-    c->plan_n_parts = n_parts;
+    c->plan_n_parts = pp.n_parts;
     c->plan_ppb = c->pairs_per_block;
     return RMX_OK;
 }
@@ -805,20 +785,18 @@ static int upload(rmx_ctx* c, float2** dst, const std::vector<float2>& v) {
 // windows up to this zero-padded length run with the whole transform in LDS (128 KiB of the 160)
 // (L = 16384 -- N = 8192, the reference's iq_stream_client capture length -- is better off in the four-step path: one
 // 128 KiB transform per CU leaves nothing to overlap with; 0.77 -> 0.60 ms for 3 buoys x 1024 windows)
-static long gen_small_max_l() {
-    static const long v = [] { const char* e = getenv("RMX_SMALL_MAXL"); const long x = e ? atol(e) : 0; return x >= 256 && x <= 16384 ? x : 8192L; }();
-    return v;
-}
-#define kGenSmallMaxL gen_small_max_l()
+static long gen_small_max_l(const rmx_ctx* c) { return c->knobs.get_or("small_maxl", 8192L); }
+#define kGenSmallMaxL gen_small_max_l(c)
 static int gen_small_threads(long L) { const long t = L >> 4; return t >= 1024 ? 1024 : (t < 64 ? 64 : (int)t); }   // one radix-16 group per thread and pass
 // dynamic LDS of the four-step kernels
-static int gen_rows_tpr(int R) {
+static int gen_rows_tpr(const rmx_ctx* c, int R) {
     int t = gen::rows_tpr(R);
-    if (const char* e = getenv("RMX_ROWS_TPR")) { const int v = atoi(e); if (v >= 1 && v <= gen::kGThreads && (v & (v - 1)) == 0 && v <= R) t = v; }
+    long v;
+    if (c->knobs.get("rows_tpr", &v) && v >= 1 && v <= gen::kGThreads && (v & (v - 1)) == 0 && v <= R) t = (int)v;
     return t;
 }
-static size_t gen_rows_lds(int R) {                     // rows + per-row twiddle tables (TW passes)
-    const int tpr = gen_rows_tpr(R);
+static size_t gen_rows_lds(const rmx_ctx* c, int R) {   // rows + per-row twiddle tables (TW passes)
+    const int tpr = gen_rows_tpr(c, R);
     int logR = 0;
     while ((1 << logR) < R) ++logR;
     const int a = logR >> 1;
@@ -930,17 +908,17 @@ static size_t gen_fused_lds(int R, bool tw_regs = false) {   // g_rows_fused: R/
     const int buf = logR == 9 ? gen::FusedPlan<9>::buf : logR == 10 ? gen::FusedPlan<10>::buf : logR == 11 ? gen::FusedPlan<11>::buf : gen::FusedPlan<12>::buf;
     return ((size_t)upw * ((size_t)buf + (1 << a) + (R >> a)) + (size_t)(tw_regs ? 0 : gen::fused_tab_total(logR))) * 8;   // + the passes' twiddle tables
 }
-static int host_col_log_t(int l1) {                     // gen::col_log_t, or RMX_COL_LOGT (3 | 4) for experiments
-    if (const char* e = getenv("RMX_COL_LOGT")) { const int v = atoi(e); if (v == 3 || v == 4) return v; }
-    return gen::col_log_t(l1);
+static int host_col_log_t(const rmx_ctx* c, int l1) {   // gen::col_log_t, or the "col_logt" option (3 | 4) for experiments
+    return (int)c->knobs.get_or("col_logt", gen::col_log_t(l1));
 }
-static size_t gen_cols_lds(int l1) {                    // [L1][T] tile + T per-column twiddle tables
-    const int a = l1 >> 1, T = 1 << host_col_log_t(l1);
+static size_t gen_cols_lds(const rmx_ctx* c, int l1) {  // [L1][T] tile + T per-column twiddle tables
+    const int a = l1 >> 1, T = 1 << host_col_log_t(c, l1);
     return ((size_t)gen::lp((long)(1 << l1) * T) + (size_t)T * ((1 << a) + ((1 << l1) >> a) + 1) + (size_t)((1 << l1) >> 1)) * 8;   // + W_L1 table
 }
-static int gen_cols_threads(int l1) {                   // one radix-16 work item per thread and pass, <= 1024
-    const long work = (((long)1 << l1) << host_col_log_t(l1)) / 16;
-    if (const char* e = getenv("RMX_COLS_THREADS")) { const int v = atoi(e); if (v >= 64 && v <= 1024) return v; }
+static int gen_cols_threads(const rmx_ctx* c, int l1) { // one radix-16 work item per thread and pass, <= 1024
+    const long work = (((long)1 << l1) << host_col_log_t(c, l1)) / 16;
+    long v;
+    if (c->knobs.get("cols_threads", &v)) return (int)v;
     return work >= 1024 ? 1024 : (work < 64 ? 64 : (int)work);
 }
 
@@ -964,7 +942,7 @@ static int generic_init(rmx_ctx* c) {
         // at most four buoys, 512 <= L <= 4096: whole windows in one kernel, spectra in registers (RMX_WFUSED=0: the two
         // kernels above, as for custom Doppler searches)
         c->g_wfused = c->n_buoys >= 2 && c->n_buoys <= 4 && c->g_logL >= 9 && c->g_logL <= 12;
-        if (const char* e = getenv("RMX_WFUSED")) c->g_wfused = c->g_wfused && atoi(e) != 0;
+        c->g_wfused = c->g_wfused && c->knobs.get_or("wfused", 1) != 0;
         if (c->g_wfused) {
             c->g_wf_fn[0][0] = wfused_fn<false, false>(c->n_buoys, c->g_logL);
             c->g_wf_fn[0][1] = wfused_fn<false, true>(c->n_buoys, c->g_logL);
@@ -984,7 +962,7 @@ static int generic_init(rmx_ctx* c) {
         if (c->g_logL == 18) c->g_logL1 = 8;   // (measured with this round's kernels: 256 x 1024 beats 128 x 2048 by 5 %)
         if (c->g_logL1 < c->g_logL - 13) c->g_logL1 = c->g_logL - 13;
         if (c->g_logL1 > 10) c->g_logL1 = 10;
-        if (const char* e = getenv("RMX_LOGL1")) { const int v = atoi(e); if (v >= 4 && v <= 10 && c->g_logL - v <= 13 && c->g_logL - v >= 4) c->g_logL1 = v; }
+        { long v; if (c->knobs.get("logl1", &v) && v >= 4 && v <= 10 && c->g_logL - v <= 13 && c->g_logL - v >= 4) c->g_logL1 = (int)v; }
         c->g_logL2 = c->g_logL - c->g_logL1;
         c->g_lo_bits = (c->g_logL + 1) / 2;
         make_row_table(t, 1 << c->g_logL1);
@@ -999,9 +977,9 @@ static int generic_init(rmx_ctx* c) {
         if (rc) return rc;
         rc = upload(c, &c->g_tlo, tlo);
         if (rc) return rc;
-        const int cols_lds = (int)gen_cols_lds(c->g_logL1), rows_lds = (int)gen_rows_lds(1 << c->g_logL2);
+        const int cols_lds = (int)gen_cols_lds(c, c->g_logL1), rows_lds = (int)gen_rows_lds(c, 1 << c->g_logL2);
         {
-            const int lt = host_col_log_t(c->g_logL1), thr = gen_cols_threads(c->g_logL1);
+            const int lt = host_col_log_t(c, c->g_logL1), thr = gen_cols_threads(c, c->g_logL1);
             c->g_cols_inv_fn = cols_inv_fn(c->g_logL1, lt, thr);
             c->g_cols_fwd_fn[0] = cols_fwd_fn<false>(c->g_logL1, lt, thr);
             c->g_cols_fwd_fn[1] = cols_fwd_fn<true>(c->g_logL1, lt, thr);
@@ -1011,26 +989,26 @@ static int generic_init(rmx_ctx* c) {
         }
         RMX_HIP(c, hipFuncSetAttribute((const void*)(g_rows<true, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, rows_lds));
         RMX_HIP(c, hipFuncSetAttribute((const void*)(g_rows<false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, rows_lds));
-        c->g_rows_inv_fn = rows_inv_fn(c->g_logL2, gen_rows_tpr(1 << c->g_logL2));
-        c->g_rows_fwd_fn = rows_fwd_fn(c->g_logL2, gen_rows_tpr(1 << c->g_logL2));
+        c->g_rows_inv_fn = rows_inv_fn(c->g_logL2, gen_rows_tpr(c, 1 << c->g_logL2));
+        c->g_rows_fwd_fn = rows_fwd_fn(c->g_logL2, gen_rows_tpr(c, 1 << c->g_logL2));
         RMX_HIP(c, hipFuncSetAttribute(c->g_rows_fwd_fn, hipFuncAttributeMaxDynamicSharedMemorySize, rows_lds));
         RMX_HIP(c, hipFuncSetAttribute(c->g_rows_inv_fn, hipFuncAttributeMaxDynamicSharedMemorySize, rows_lds));
-        c->g_rows_anchor_fn = rows_anchor_fn(c->g_logL2, gen_rows_tpr(1 << c->g_logL2));
-        if (const char* e = getenv("RMX_ROWS_ANCHOR")) { const int v = atoi(e); if (v == 0) c->g_rows_anchor_fn = nullptr; else if (v >= 2) c->g_rows_anchor_min_b = v; }
+        c->g_rows_anchor_fn = rows_anchor_fn(c->g_logL2, gen_rows_tpr(c, 1 << c->g_logL2));
+        { long v; if (c->knobs.get("rows_anchor", &v)) { if (v == 0) c->g_rows_anchor_fn = nullptr; else if (v >= 2) c->g_rows_anchor_min_b = (int)v; } }
         if (c->g_rows_anchor_fn)
             RMX_HIP(c, hipFuncSetAttribute(c->g_rows_anchor_fn, hipFuncAttributeMaxDynamicSharedMemorySize, rows_lds));
         // both row passes in one kernel when the buoys' spectra rows fit the register file (generic_path.hpp)
         c->g_fused = c->n_buoys <= 4 && c->g_logL2 >= 9 && c->g_logL2 <= 12;
-        if (const char* e = getenv("RMX_FUSED")) {      // 0: never, 2: also for batches too small to fill the chip (tests)
-            c->g_fused = c->g_fused && atoi(e) != 0;
-            c->g_fused_always = atoi(e) == 2;
-        }
+        { long v; if (c->knobs.get("fused", &v)) {      // 0: never, 2: also for batches too small to fill the chip (tests)
+            c->g_fused = c->g_fused && v != 0;
+            c->g_fused_always = v == 2;
+        } }
         if (c->g_fused) {
             const int flds = (int)gen_fused_lds(1 << c->g_logL2);
             const void* fn = fused_fn(c->n_buoys, c->g_logL2, false);
             c->g_fused_fn = fn;
             c->g_fused_def_fn = fused_fn(c->n_buoys, c->g_logL2, true);
-            if (const char* e = getenv("RMX_FUSED_DEF")) { if (atoi(e) == 0) c->g_fused_def_fn = nullptr; }
+            if (c->knobs.get_or("fused_def", 1) == 0) c->g_fused_def_fn = nullptr;
             if (c->g_fused_def_fn) {
                 const int dlds = (int)gen_fused_lds(1 << c->g_logL2, gen::fused_tw_regs(c->n_buoys, c->g_logL2, true));
                 RMX_HIP(c, hipFuncSetAttribute(c->g_fused_def_fn, hipFuncAttributeMaxDynamicSharedMemorySize, dlds));
@@ -1041,10 +1019,10 @@ static int generic_init(rmx_ctx* c) {
     // any buoy count, 512 <= L <= 16384: whole windows in one persistent kernel, spectra in a per-workgroup scratch
     // (RMX_WSCR=0: the two-kernel LDS path / the four-step path, which the Doppler search uses in any case)
     c->g_wscr = !c->g_wfused && c->g_logL >= 9 && c->g_logL <= 14;
-    if (const char* e = getenv("RMX_WSCR")) {          // 0: never, 2: also for batches that do not fill the chip (tests)
-        c->g_wscr = c->g_wscr && atoi(e) != 0;
-        c->g_wscr_always = atoi(e) == 2;
-    }
+    { long v; if (c->knobs.get("wscr", &v)) {          // 0: never, 2: also for batches that do not fill the chip (tests)
+        c->g_wscr = c->g_wscr && v != 0;
+        c->g_wscr_always = v == 2;
+    } }
     if (c->g_wscr) {
         make_row_table(t, (int)L);
         int rc = upload(c, &c->g_tw_win, t);
@@ -1054,7 +1032,7 @@ static int generic_init(rmx_ctx* c) {
         wscr_shape(c->g_logL, &c->g_ws_thr, &c->g_ws_upw, &c->g_ws_lds);
         // L = 16384: 512 threads x two butterflies (g_win_scr14) unless RMX_WSCR14=0 (1024 threads x one: g_win_scr<14>)
         bool two = c->g_logL == 14;
-        if (const char* e = getenv("RMX_WSCR14")) two = two && atoi(e) != 0;
+        two = two && c->knobs.get_or("wscr14", 1) != 0;
         if (two) {
             c->g_ws_fn[0] = (const void*)gen::g_win_scr14<false>;
             c->g_ws_fn[1] = (const void*)gen::g_win_scr14<true>;
@@ -1066,7 +1044,7 @@ static int generic_init(rmx_ctx* c) {
             RMX_HIP(c, hipFuncSetAttribute(c->g_ws_fn[u], hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->g_ws_lds));
         RMX_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, c->g_ws_fn[0], c->g_ws_thr, c->g_ws_lds));
         if (per_cu < 1) per_cu = 1;
-        if (const char* e = getenv("RMX_WSCR_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= per_cu) per_cu = v; }
+        { long v; if (c->knobs.get("wscr_per_cu", &v) && v >= 1 && v <= per_cu) per_cu = (int)v; }
         long grid = (long)c->n_cus * per_cu;
         const long need = ((long)c->max_windows + c->g_ws_upw - 1) / c->g_ws_upw;
         if (grid > need) grid = need;
@@ -1075,40 +1053,60 @@ static int generic_init(rmx_ctx* c) {
         RMX_HIP(c, hipMalloc((void**)&c->g_ws_scratch, sbytes));
         c->scratch_bytes += sbytes;
     }
-    // windows per chunk: spectra (B*L) + products (P*L), 8 bytes each, under 32 GiB of the 288 (cfg2's 64
-    // windows of 2^20 samples are one chunk of 6.4 GB)
-    const long per_win = (long)(c->n_buoys + all_pairs) * L * 8;
-    long chunk = (32L << 30) / per_win;
-    if (chunk < 1) chunk = 1;
-    if (chunk > c->max_windows) chunk = c->max_windows;
-    if (chunk > 4096) chunk = 4096;
-    if (const char* e = getenv("RMX_GEN_CHUNK")) { const long v = atol(e); if (v >= 1 && v < chunk) chunk = v; }   // experiments
+    // windows per chunk (host_plan.hpp: spectra + products under 32 GiB of the 288, "gen_chunk" caps it for experiments)
+    const long chunk = host::generic_chunk_windows(c->n_buoys, L, c->max_windows, 32L << 30, c->knobs.get_or("gen_chunk", 0));
     c->g_chunk = (int)chunk;
     return RMX_OK;
 }
 
-static int generic_ensure(rmx_ctx* c, int n_pairs, bool need_spec = true) {
+// Device buffers of the generic path, allocated on first need:
+//   need_spec      the per-window spectra (two-kernel LDS path, four-step path, Doppler search)
+//   need_pairbufs  products / tile records / halo of the FOUR-STEP pair kernels -- not when the whole-window kernels
+//                  run (g_win_fused, g_win_scr never touch them: an 8-buoy, 4096-window engine of 8192-sample windows
+//                  would otherwise pin 15 GB it never uses)
+// A failed hipMalloc halves the chunk and retries (down to one window) instead of giving up.
+static int generic_ensure(rmx_ctx* c, int n_pairs, bool need_spec = true, bool need_pairbufs = true) {
     using namespace gen;
     const long L = 1L << c->g_logL;
-    const long items = (long)c->g_chunk * c->n_buoys, slots = (long)c->g_chunk * n_pairs;
-    if (!c->g_spec && need_spec) {
-        RMX_HIP(c, hipMalloc((void**)&c->g_spec, items * L * 8));
-        c->scratch_bytes += items * L * 8;
-    }
-    if (L > kGenSmallMaxL) {
-        // (re)allocate the pair-dependent buffers when the pair count grows
-        if (slots > c->g_slots_alloc) {
-            if (c->g_prod) { (void)hipFree(c->g_prod); c->g_prod = nullptr; }
-            if (c->g_rec) { (void)hipFree(c->g_rec); c->g_rec = nullptr; }
-            if (c->g_halo) { (void)hipFree(c->g_halo); c->g_halo = nullptr; }
+    const bool four_step = L > kGenSmallMaxL;
+    auto release = [&]() {
+        for (void** p : {(void**)&c->g_spec, (void**)&c->g_spec_r, (void**)&c->g_prod, (void**)&c->g_rec, (void**)&c->g_halo})
+            if (*p) { (void)hipFree(*p); *p = nullptr; }
+        c->scratch_bytes -= c->g_dyn_bytes;
+        c->g_dyn_bytes = 0;
+        c->g_slots_alloc = 0;
+    };
+    for (;;) {
+        const long items = (long)c->g_chunk * c->n_buoys, slots = (long)c->g_chunk * n_pairs;
+        bool ok = true;
+        auto grab = [&](void** p, size_t bytes) {
+            if (!ok) return;
+            if (hipMalloc(p, bytes) != hipSuccess) { (void)hipGetLastError(); *p = nullptr; ok = false; return; }
+            c->scratch_bytes += bytes;
+            c->g_dyn_bytes += bytes;
+        };
+        if (!c->g_spec && need_spec) grab((void**)&c->g_spec, (size_t)items * L * 8);
+        if (four_step && need_pairbufs && slots > c->g_slots_alloc) {
+            // (re)allocate the pair-dependent buffers when the pair count grows
+            for (void** p : {(void**)&c->g_prod, (void**)&c->g_rec, (void**)&c->g_halo})
+                if (*p) { (void)hipFree(*p); *p = nullptr; }
+            c->scratch_bytes -= c->g_pair_bytes;
+            c->g_dyn_bytes -= c->g_pair_bytes;
+            c->g_pair_bytes = 0;
             c->g_slots_alloc = 0;
-            RMX_HIP(c, hipMalloc((void**)&c->g_prod, slots * L * 8));
-            const long parts = (1L << c->g_logL2) >> host_col_log_t(c->g_logL1);   // one record per column tile
-            RMX_HIP(c, hipMalloc((void**)&c->g_rec, slots * parts * sizeof(GTile)));
-            RMX_HIP(c, hipMalloc((void**)&c->g_halo, slots * parts * 2 * sizeof(float) << c->g_logL1));
-            c->scratch_bytes += slots * L * 8 + slots * parts * (sizeof(GTile) + (2 * sizeof(float) << c->g_logL1));
-            c->g_slots_alloc = slots;
+            const size_t before = c->g_dyn_bytes;
+            const long parts = (1L << c->g_logL2) >> host_col_log_t(c, c->g_logL1);   // one record per column tile
+            grab((void**)&c->g_prod, (size_t)slots * L * 8);
+            grab((void**)&c->g_rec, (size_t)slots * parts * sizeof(GTile));
+            grab((void**)&c->g_halo, (size_t)slots * parts * 2 * sizeof(float) << c->g_logL1);
+            c->g_pair_bytes = c->g_dyn_bytes - before;
+            if (ok) c->g_slots_alloc = slots;
         }
+        if (ok) break;
+        if (c->g_chunk <= 1) { release(); return fail(c, RMX_E_NOMEM, "device allocation failed even for one window per chunk"); }
+        RMX_HIP(c, hipStreamSynchronize(c->stream));
+        release();                                    // every chunk-sized buffer goes; they come back at half the size
+        c->g_chunk = (c->g_chunk + 1) / 2;
     }
     if (c->g_pairs_n == n_pairs && c->g_pairs_plan == c->plan_pairs) return RMX_OK;
     if (c->g_pairs) { (void)hipFree(c->g_pairs); c->g_pairs = nullptr; }
@@ -1135,6 +1133,7 @@ static int generic_forward(rmx_ctx* c, const void* d_iq, int w0, int wc, bool u8
     if (rot && !c->g_spec_r) {
         RMX_HIP(c, hipMalloc((void**)&c->g_spec_r, (size_t)c->g_chunk * B * L * 8));
         c->scratch_bytes += (size_t)c->g_chunk * B * L * 8;
+        c->g_dyn_bytes += (size_t)c->g_chunk * B * L * 8;
     }
     float2* dst = rot ? c->g_spec_r : c->g_spec;
     if (L <= kGenSmallMaxL) {
@@ -1149,9 +1148,9 @@ static int generic_forward(rmx_ctx* c, const void* d_iq, int w0, int wc, bool u8
         return RMX_OK;
     }
     const int l1 = c->g_logL1, l2 = c->g_logL2, L1 = 1 << l1, L2 = 1 << l2;
-    const int cthr = gen_cols_threads(l1), tpr = gen_rows_tpr(L2);
-    const size_t clds = gen_cols_lds(l1), rlds = gen_rows_lds(L2);
-    const int lt = host_col_log_t(l1), ntiles = L2 >> lt;
+    const int cthr = gen_cols_threads(c, l1), tpr = gen_rows_tpr(c, L2);
+    const size_t clds = gen_cols_lds(c, l1), rlds = gen_rows_lds(c, L2);
+    const int lt = host_col_log_t(c, l1), ntiles = L2 >> lt;
     // column pass (zero-padded window -> [k1'][n2] * W_L^(n2 k1)), row pass in place (-> [k1'][k2'])
     {
         const void* a_iq = d_iq;
@@ -1203,9 +1202,9 @@ static int generic_pairs(rmx_ctx* c, int w0, int wc, int n_pairs, int* d_lag, fl
         return RMX_OK;
     }
     const int l1 = c->g_logL1, l2 = c->g_logL2, L1 = 1 << l1, L2 = 1 << l2;
-    const int cthr = gen_cols_threads(l1), tpr = gen_rows_tpr(L2);
-    const size_t clds = gen_cols_lds(l1), rlds = gen_rows_lds(L2);
-    const int lt = host_col_log_t(l1), ntiles = L2 >> lt;
+    const int cthr = gen_cols_threads(c, l1), tpr = gen_rows_tpr(c, L2);
+    const size_t clds = gen_cols_lds(c, l1), rlds = gen_rows_lds(c, L2);
+    const int lt = host_col_log_t(c, l1), ntiles = L2 >> lt;
     const long rows = (long)slots * L1;
     const int rpw = kGThreads / tpr;
     // row pass ([product on load] rows(L2)^-1 * conj W_L^(n2 k1)), column pass (-> tile records + halo), reduction
@@ -1271,7 +1270,8 @@ static int generic_batch(rmx_ctx* c, const void* d_iq, int n_windows, int n_pair
     // Measured crossovers (tools/smallw.sh): 0.43 workgroups per CU at L = 16384 (8 buoys; 0.63 with 3), 0.66 .. 0.68 below
     const long ws_blocks = ((long)n_windows + (c->g_ws_upw > 0 ? c->g_ws_upw : 1) - 1) / (c->g_ws_upw > 0 ? c->g_ws_upw : 1);
     const bool use_wscr = c->g_wscr && (c->g_wscr_always || ws_blocks >= (c->g_logL == 14 ? 7L : 11L) * c->n_cus / 16);
-    int rc = generic_ensure(c, n_pairs, !c->g_wfused && !use_wscr);
+    const bool whole_window = c->g_wfused || use_wscr;   // those kernels keep no per-window state in HBM
+    int rc = generic_ensure(c, n_pairs, !whole_window, !whole_window);
     if (rc) return rc;
     if (use_wscr) {
         const int logL = c->g_logL, hs = logL / 2;
@@ -1343,15 +1343,16 @@ int rmx_create(rmx_ctx** out, int device_id, int n_buoys, int n_samples, int max
     if (!out) return fail(nullptr, RMX_E_INVAL, "out is NULL");
     *out = nullptr;
     (void)flags;
-    if (n_buoys < 2 || n_buoys > 4096) return fail(nullptr, RMX_E_INVAL, "n_buoys %d not in 2..4096", n_buoys);
-    if (!is_pow2(n_samples) || n_samples < 16 || n_samples > (1 << 22))
-        return fail(nullptr, RMX_E_INVAL, "n_samples %d must be a power of two in 16..4194304", n_samples);
-    if (max_windows < 1) return fail(nullptr, RMX_E_INVAL, "max_windows %d < 1", max_windows);
+    {
+        std::string why;
+        if (host::check_create_args(n_buoys, n_samples, max_windows, &why) != 0) return fail(nullptr, RMX_E_INVAL, "%s", why.c_str());
+    }
     int ndev = rmx_device_count();
     if (ndev <= 0) return fail(nullptr, RMX_E_NODEV, "no HIP device visible");
     if (device_id < 0 || device_id >= ndev) return fail(nullptr, RMX_E_INVAL, "device_id %d not in 0..%d", device_id, ndev - 1);
     rmx_ctx* c = new (std::nothrow) rmx_ctx();
     if (!c) return fail(nullptr, RMX_E_NOMEM, "host allocation failed");
+    c->knobs = host::snapshot_default_options();   // options set later do not reach this ctx
     c->device = device_id;
     c->n_buoys = n_buoys;
     c->n_samples = n_samples;
@@ -1369,14 +1370,13 @@ int rmx_create(rmx_ctx** out, int device_id, int n_buoys, int n_samples, int max
             if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && ncu > 0)
                 c->n_cus = ncu;
             // experiment knob: fewer persistent workgroups than CUs (per-CU time without chip-wide contention)
-            if (const char* e = getenv("RMX_NCUS")) { const int v = atoi(e); if (v > 0 && v < c->n_cus) c->n_cus = v; }
+            { long v; if (c->knobs.get("ncus", &v) && v > 0 && v < c->n_cus) c->n_cus = (int)v; }
         }
         RMX_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         c->own_stream = true;
-        // (RMX_GENERIC4096=1: N = 4096 through the generic kernels too -- g_win_scr<13> against k_win, an experiment)
-        if (n_samples != kM || (getenv("RMX_GENERIC4096") && atoi(getenv("RMX_GENERIC4096")) != 0)) return rmx::generic_init(c);
-        const char* env = getenv("RMX_CHUNK_WINDOWS");
-        int chunk = env ? atoi(env) : 4096;
+        // (option generic4096 = 1: N = 4096 through the generic kernels too -- g_win_scr<13> against k_win, an experiment)
+        if (n_samples != kM || c->knobs.get_or("generic4096", 0) != 0) return rmx::generic_init(c);
+        int chunk = (int)c->knobs.get_or("chunk_windows", 4096);
         if (chunk < 8) chunk = 8;
         chunk = (chunk + 7) & ~7;
         if (chunk > max_windows) chunk = max_windows;
@@ -1401,7 +1401,9 @@ int rmx_create(rmx_ctx** out, int device_id, int n_buoys, int n_samples, int max
         RMX_HIP(c, hipMemcpy(c->d_tw1, tw1.data(), tw1.size() * sizeof(float4), hipMemcpyHostToDevice));
         RMX_HIP(c, hipMemcpy(c->d_tw2, tw2.data(), tw2.size() * sizeof(float2), hipMemcpyHostToDevice));
         c->scratch_bytes = c->spec_bytes + tw1.size() * sizeof(float4) + tw2.size() * sizeof(float2);
-        {
+        c->stag = (int)c->knobs.get_or("stag", 1);
+#ifdef RMX_EXPERIMENTS
+        {   // the two other builds of the fused kernel: measured slower, not in the default build
             std::vector<float4> t1;
             std::vector<float2> tb, tc;
             build_tables8(t1, tb, tc);
@@ -1416,10 +1418,10 @@ int rmx_create(rmx_ctx** out, int device_id, int n_buoys, int n_samples, int max
             RMX_HIP(c, hipFuncSetAttribute((const void*)w8::k_win8<true>, hipFuncAttributeMaxDynamicSharedMemorySize, w8::kLdsWin8Bytes));
             RMX_HIP(c, hipFuncSetAttribute((const void*)k_winp<false>, hipFuncAttributeMaxDynamicSharedMemorySize, pk::kLdsWinpBytes));
             RMX_HIP(c, hipFuncSetAttribute((const void*)k_winp<true>, hipFuncAttributeMaxDynamicSharedMemorySize, pk::kLdsWinpBytes));
-            if (const char* e = getenv("RMX_PK")) c->pk = atoi(e);
-            if (const char* e = getenv("RMX_WIN8")) c->win8 = atoi(e);
-            if (const char* e = getenv("RMX_STAG")) c->stag = atoi(e);
+            c->pk = (int)c->knobs.get_or("pk", 0);
+            c->win8 = (int)c->knobs.get_or("win8", 0);
         }
+#endif
         RMX_HIP(c, hipFuncSetAttribute((const void*)k_fwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
         RMX_HIP(c, hipFuncSetAttribute((const void*)k_fwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
         RMX_HIP(c, hipFuncSetAttribute((const void*)k_pair_res, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsResBytes));
@@ -1478,6 +1480,14 @@ int rmx_set_stream(rmx_ctx* c, void* hip_stream) {
     return RMX_OK;
 }
 
+int rmx_set_default_option(const char* key, long value) {
+    std::string why;
+    if (host::set_default_option(key, value, &why) != 0) return fail(nullptr, RMX_E_INVAL, "%s", why.c_str());
+    return RMX_OK;
+}
+
+void rmx_clear_default_options(void) { host::clear_default_options(); }
+
 int rmx_set_option(rmx_ctx* c, const char* key, long value) {
     if (!c || !key) return RMX_E_INVAL;
     if (!strcmp(key, "chunk_windows")) {
@@ -1506,13 +1516,13 @@ int rmx_set_option(rmx_ctx* c, const char* key, long value) {
         return fail(c, RMX_E_UNSUPPORTED, "option 'dbg' exists only in the -DRMX_ABLATE timing build");
 #endif
     }
-    if (!strcmp(key, "pk")) {
-        c->pk = value != 0;
+    if (!strcmp(key, "pk") || !strcmp(key, "win8")) {
+#ifdef RMX_EXPERIMENTS
+        (key[0] == 'p' ? c->pk : c->win8) = value != 0;
         return RMX_OK;
-    }
-    if (!strcmp(key, "win8")) {
-        c->win8 = value != 0;
-        return RMX_OK;
+#else
+        return fail(c, RMX_E_UNSUPPORTED, "option '%s' exists only in the -DRMX_EXPERIMENTS build (k_win8 / k_winp)", key);
+#endif
     }
     if (!strcmp(key, "stag")) {
         if (value < 0 || value > 5) return fail(c, RMX_E_INVAL, "stag %ld not in 0..5", value);
@@ -1722,6 +1732,7 @@ int rmx_xcorr_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pa
                 // one persistent workgroup per CU (the kernel's LDS footprint allows exactly one)
                 const int wgrid = sc < c->n_cus ? sc : c->n_cus;
                 if (c->timing) RMX_HIP(c, hipEventRecord(c->ev[c->ev_used], c->stream));
+#ifdef RMX_EXPERIMENTS
                 if (c->win8) {
                     if (u8)
                         hipLaunchKernelGGL(w8::k_win8<true>, dim3(wgrid), dim3(w8::kT8), w8::kLdsWin8Bytes, c->stream, d_iq,
@@ -1738,7 +1749,9 @@ int rmx_xcorr_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pa
                     else
                         hipLaunchKernelGGL(k_winp<false>, dim3(wgrid), dim3(kThreads), pk::kLdsWinpBytes, c->stream, d_iq, c->d_spec,
                                            c->d_tw1, c->d_tw2, c->n_buoys, wfirst, out_scale, d_lag, d_frac, d_peak, sc);
-                } else if (u8)
+                } else
+#endif
+                if (u8)
                     hipLaunchKernelGGL(k_win<true>, dim3(wgrid), dim3(kThreads), kLdsWinBytes, c->stream, d_iq, c->d_spec,
                                        c->d_tw1, c->d_tw2, c->n_buoys, wfirst, out_scale, d_lag, d_frac,
                                        d_peak, sc, c->dbg, c->stag);

@@ -61,6 +61,10 @@ def load_library():
     lib.rmx_set_stream.restype = ci
     lib.rmx_set_option.argtypes = [vp, C.c_char_p, C.c_long]
     lib.rmx_set_option.restype = ci
+    lib.rmx_set_default_option.argtypes = [C.c_char_p, C.c_long]
+    lib.rmx_set_default_option.restype = ci
+    lib.rmx_clear_default_options.argtypes = []
+    lib.rmx_clear_default_options.restype = None
     lib.rmx_xcorr_batch.argtypes = [vp, vp, ci, vp, ci, vp, vp, vp, cu]
     lib.rmx_xcorr_batch.restype = ci
     lib.rmx_caf_batch.argtypes = [vp, vp, ci, vp, ci, vp, ci, vp, vp, vp, vp, cu]
@@ -81,8 +85,37 @@ def load_library():
 
 
 EXPORTS = ["rmx_version", "rmx_device_count", "rmx_create", "rmx_destroy", "rmx_last_error",
-           "rmx_set_stream", "rmx_set_option", "rmx_xcorr_batch", "rmx_caf_batch", "rmx_solve_batch", "rmx_detect_batch", "rmx_synchronize",
+           "rmx_set_stream", "rmx_set_option", "rmx_set_default_option", "rmx_clear_default_options", "rmx_xcorr_batch", "rmx_caf_batch", "rmx_solve_batch", "rmx_detect_batch", "rmx_synchronize",
            "rmx_last_timing", "rmx_scratch_bytes"]
+
+
+def set_default_option(key: str, value: int) -> None:
+    """Kernel-selection default for engines created afterwards (rmx_set_default_option: tests and A/B runs)."""
+    lib = load_library()
+    if lib.rmx_set_default_option(key.encode(), int(value)) != 0:
+        msg = lib.rmx_last_error(None)
+        raise RmxError(-1, msg.decode() if msg else "rmx_set_default_option failed")
+
+
+def clear_default_options() -> None:
+    load_library().rmx_clear_default_options()
+
+
+def apply_env_options(environ=None) -> dict:
+    """For the tools/ scripts only: turns RMX_<KEY>=<int> environment variables into default options (the library
+    itself never reads the environment).  Returns what was applied."""
+    import os as _os
+    env = _os.environ if environ is None else environ
+    done = {}
+    for k, v in env.items():
+        if not k.startswith("RMX_") or k in ("RMX_LIBRARY", "RMX_CPU_THREADS") or k.startswith("RMX_BENCH"):
+            continue
+        try:
+            set_default_option(k[4:].lower(), int(v))
+            done[k[4:].lower()] = int(v)
+        except (RmxError, ValueError):
+            pass
+    return done
 
 
 def device_count() -> int:

@@ -78,3 +78,21 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+
+
+def test_default_options_are_validated_and_never_come_from_the_environment(lib, monkeypatch):
+    """rmx_set_default_option: unknown keys and out-of-range values are refused with text; the library reads no
+    RMX_* environment variable (the strings do not even occur in it)."""
+    from radio_mapper_amd import xcorr
+    assert lib.rmx_set_default_option(b"wscr", 2) == 0
+    assert lib.rmx_set_default_option(b"wscr", 9) == -1 and b"not in 0..2" in lib.rmx_last_error(None)
+    assert lib.rmx_set_default_option(b"nope", 1) == -1 and b"unknown option" in lib.rmx_last_error(None)
+    lib.rmx_clear_default_options()
+    with pytest.raises(xcorr.RmxError):
+        xcorr.set_default_option("stag", 17)
+    xcorr.set_default_option("stag", 0)
+    assert xcorr.apply_env_options({"RMX_WSCR": "2", "RMX_LIBRARY": "x", "RMX_NOPE": "1", "RMX_FUSED": "zz", "HOME": "/"}) == {"wscr": 2}
+    xcorr.clear_default_options()
+    blob = open(xcorr.library_path(), "rb").read()
+    assert b"getenv" not in blob or all(k not in blob for k in (b"RMX_WSCR", b"RMX_FUSED", b"RMX_STAG", b"RMX_NCUS", b"RMX_COL_LOGT"))
+    assert all(k not in blob for k in (b"RMX_WSCR", b"RMX_FUSED", b"RMX_STAG", b"RMX_NCUS", b"RMX_COL_LOGT", b"RMX_ROWS_TPR"))

@@ -8,7 +8,7 @@ import torch
 from radio_mapper_amd import xcorr
 
 def run(B, N, W, fused):
-    os.environ["RMX_FUSED"] = "2" if fused else "0"
+    xcorr.set_default_option("fused", int("2" if fused else "0"))
     dev = torch.device("cuda", 0)
     g = torch.Generator(device=dev); g.manual_seed(11 + B + N)
     base = torch.randn((W, 1, N + 4096, 2), device=dev, generator=g) * 20.0

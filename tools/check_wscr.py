@@ -10,15 +10,15 @@ import torch
 from radio_mapper_amd import xcorr, synth
 
 def run(iq, pairs, on, N):
-    os.environ["RMX_WFUSED"] = "0"
-    os.environ["RMX_WSCR"] = "2" if on else "0"
+    xcorr.set_default_option("wfused", int("0"))
+    xcorr.set_default_option("wscr", int("2" if on else "0"))
     W, B = iq.shape[:2]
     with xcorr.XcorrEngine(B, N, W) as eng:
         return eng.correlate(iq, pairs)
 
 def timeit(B, N, W, on, wf="1"):
-    os.environ["RMX_WFUSED"] = wf
-    os.environ["RMX_WSCR"] = "2" if on else "0"
+    xcorr.set_default_option("wfused", int(wf))
+    xcorr.set_default_option("wscr", int("2" if on else "0"))
     dev = torch.device("cuda", 0)
     g = torch.Generator(device=dev); g.manual_seed(3)
     x = torch.randn((W, B, N, 2), device=dev, generator=g) * 30.0

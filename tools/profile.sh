@@ -26,10 +26,3 @@ for set in "${sets[@]}"; do
 done
 ls -R "$out" | head -50
 exit 0
-for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_ACTIVE_INST_VALU" \
-           "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU" \
-           "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum"; do
-  name=$(echo $set | tr ' ' '_' | cut -c1-40)
-  rocprofv3 --pmc $set -T -f csv -d "$out/pmc_$name" -o pmc -- $BENCH > "$out/pmc_$name.log" 2>&1 || echo "pmc $name failed"
-done
-ls -R "$out" | head -50
