@@ -134,7 +134,8 @@ __device__ __forceinline__ void resolve_batch(int lane, const float4* red, const
 // diagnostic build (tools/probe/kwin_bench.hip -DRMX_KWIN_STAMPS): shader-clock stamps of workgroup's wave 0 at the phase
 // boundaries of every window it processes; no stamp exists in the product build
 __device__ long long rmx_stamps[256 * 64 * 4];
-__device__ int rmx_stamps_vm[256 * 64 * 8];   // per wave: ticks spent in the vmcnt wait at the head of h1, summed over the window's pairs
+__device__ int rmx_stamps_vm[256 * 64 * 8];
+__device__ int rmx_stamps_bar[256 * 64 * 8 * 2];   // per wave: ticks draining its LDS stores in front of the barriers / waiting at them   // per wave: ticks spent in the vmcnt wait at the head of h1, summed over the window's pairs
 #define RMX_STAMP(slot)                                                                              \
     do {                                                                                             \
         if (t == 0 && (wl / (int)gridDim.x) < 64)                                                    \
@@ -182,7 +183,15 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
     load_tw2_to_lds_grouped(tw2_lds, tw2_g, t);
     float2 tw1[16];
     load_tw1(tw1, tw1_g, t);
+#ifndef RMX_KWIN_LDS1
+    // second-generation exchanges (fft_r16.hpp): roles B and C keep their own digit (n0 / k1) in lane bits 0-3
+    const float4* tw2row = reinterpret_cast<const float4*>(tw2_lds + (t & 15) * kTw2RowF2);
+    const int loc_m0[2] = {__builtin_amdgcn_readfirstlane(wave * kLocWave),                 // this wave's region of image 0 / 1
+                           __builtin_amdgcn_readfirstlane(kLdsWinImg + wave * kLocWave)};
+    const int loc_rd = wave * kLocWave + loc_read_off(lane);
+#else
     const float4* tw2row = reinterpret_cast<const float4*>(tw2_lds + (u & 15) * kTw2RowF2);
+#endif
     const float sgn = p ? -1.0f : 1.0f;
     const int kbase = p ? (u - 1) : (u + kM - 1);
     const int hl = lane < 2 ? lane : lane - 60;            // halo row of lanes 0,1,62,63
@@ -217,12 +226,24 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
     int npair = 0;       // pair counter: selects the record slot (ring of kResSlots)
     int npend = 0;       // pairs whose records await a resolve
 #ifdef RMX_KWIN_STAMPS
-    int stamp_vm = 0;
+    int stamp_vm = 0, stamp_drain = 0, stamp_bar = 0;
 #endif
 
 
     auto barrier_hook = [&](bool flush) __attribute__((always_inline)) {
+#ifdef RMX_KWIN_STAMPS
+        {   // how long does this wave wait for its own LDS stores to drain, and then at the barrier for the others?
+            const long long c0 = __builtin_readcyclecounter();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const long long c1 = __builtin_readcyclecounter();
+            __syncthreads();
+            const long long c2 = __builtin_readcyclecounter();
+            stamp_drain += (int)(c1 - c0);
+            stamp_bar += (int)(c2 - c1);
+        }
+#else
         if (!(dbg & 1)) __syncthreads();
+#endif
         if (npend == kResBatch || (flush && npend > 0)) {
             if (!(dbg & 2) && !(dbg & 256) && wave == (seq & 7))
                 resolve_batch(lane, red, halo, oidx, (npair - npend) & (kResSlots - 1), npend, obase, out_scale, lag_int,
@@ -354,17 +375,29 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
         mul_w32_odd(x);            // odd sub-transform input x*W32^q (W_L^u is folded into tw1)
         dft16(x);
         mul_tw1(x, tw1);
+#ifndef RMX_KWIN_LDS1
+        if (!(dbg & 8)) xchg_a2_write(img, x, t);
+        barrier_hook(false);
+        if (!(dbg & 8)) xchg_b2_read(img, x, t);
+#else
         if (!(dbg & 8)) xchg_a_write(img, x, t);
         barrier_hook(false);
         if (!(dbg & 8)) xchg_b_read(img, x, t);
+#endif
         dft16(x);
 #ifdef RMX_TW2_LDS
         const float4 r0 = tw2row[0], r1 = tw2row[1];   // ahead of the exchange reads (see dft16_tw_row_l1)
 #endif
         if (!(dbg & 4)) {
+#ifndef RMX_KWIN_LDS1
+        loc_write16(loc_m0[seq & 1], x);
+        wave_lds_order();
+        loc_read16(smem + (seq & 1) * kLdsWinImg + loc_rd, x);
+#else
         xchg_bc_write_b(img, x, t);
         wave_lds_order();
         xchg_bc_read_c(img, x, t);
+#endif
         }
 #ifndef RMX_TW2_LDS
         dft16_tw<true>(x, tw2r);
@@ -408,14 +441,19 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
         {   // layer 2 group by group: each group's outputs go to the wave-local image at once, and a
             // quarter of the next spectra is requested behind it
             float2* wb = img + (u >> 4) * kBcHalf + (u & 15) * kBcRow + p;
+            (void)wb;
             dft16_layer2_emit(v, [&](auto kac, const float2& x0, const float2& x1, const float2& x2, const float2& x3)
                                      __attribute__((always_inline)) {
                 constexpr int ka = decltype(kac)::value;
                 if (!(dbg & 4)) {
+#ifndef RMX_KWIN_LDS1
+                    loc_write4<ka, ka + 4, ka + 8, ka + 12>(loc_m0[tr & 1], x0, x1, x2, x3);
+#else
                     wb[2 * ka] = make_float2(x0.x, x0.y);
                     wb[2 * (ka + 4)] = make_float2(x1.x, x1.y);
                     wb[2 * (ka + 8)] = make_float2(x2.x, x2.y);
                     wb[2 * (ka + 12)] = make_float2(x3.x, x3.y);
+#endif
                 }
                 if (!(dbg & 16)) prefetch(kac);
             });
@@ -425,7 +463,11 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
 #endif
         if (!(dbg & 4)) {
             wave_lds_order();
+#ifndef RMX_KWIN_LDS1
+            loc_read16(smem + (tr & 1) * kLdsWinImg + loc_rd, v);
+#else
             xchg_bc_read_b(img, v, t);
+#endif
         }
 #ifndef RMX_TW2_LDS
         dft16_tw_l1<true>(v, tw2r);
@@ -433,7 +475,11 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
         dft16_tw_row_l1(v, tw2row, r0, r1);      // W_256^(n0*k1), k1 -> n1   (role B), layer 1
 #endif
         {
+#ifndef RMX_KWIN_LDS1
+            float2* xb = img + xb2_base(t);                             // own k0 row of the [k0][n1][p][n0] image
+#else
             float2* xb = img + (u >> 4) * kBcHalf + (u & 15) * 2 + p;   // own half-wave regions
+#endif
             dft16_layer2_emit(v, [&](auto kac, const float2& x0, const float2& x1, const float2& x2, const float2& x3)
                                      __attribute__((always_inline)) {
                 constexpr int ka = decltype(kac)::value;
@@ -453,7 +499,11 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
         const float2* img = (tr & 1) ? img1 : img0;
         const int rb = npair & (kResSlots - 1);
         float2 v[16];
+#ifndef RMX_KWIN_LDS1
+        if (!(dbg & 8)) xchg_a2_read(img, v, t);
+#else
         if (!(dbg & 8)) xchg_a_read(img, v, t);
+#endif
         dft16_tw<false>(v, tw1);                 // W_M^(u*k0) [* W_L^u odd], k0 -> n2   (role A)
         mul_w32_odd(v);                          // odd lanes: * W32^q
         // last radix-2 stage across the lane pair, up to a sign that |.| does not see:
@@ -653,7 +703,11 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
     }
     RMX_STAMP(2);
 #ifdef RMX_KWIN_STAMPS
-    if (lane == 0 && (wl / (int)gridDim.x) < 64) rmx_stamps_vm[((int)blockIdx.x * 64 + wl / (int)gridDim.x) * 8 + wave] = stamp_vm;
+    if (lane == 0 && (wl / (int)gridDim.x) < 64) {
+        rmx_stamps_vm[((int)blockIdx.x * 64 + wl / (int)gridDim.x) * 8 + wave] = stamp_vm;
+        rmx_stamps_bar[(((int)blockIdx.x * 64 + wl / (int)gridDim.x) * 8 + wave) * 2] = stamp_drain;
+        rmx_stamps_bar[(((int)blockIdx.x * 64 + wl / (int)gridDim.x) * 8 + wave) * 2 + 1] = stamp_bar;
+    }
 #endif
     seq = 0;   // any wave may resolve the last pairs; take wave 0
     barrier_hook(true);

@@ -196,6 +196,16 @@ int main(int argc, char** argv) {
                 printf("    vmcnt wait at the head of h1, ticks per window, waves 0..7:");
                 for (int w8 = 0; w8 < 8; ++w8) printf(" %.0f", wv[w8] / n);
                 printf("\n");
+                std::vector<int> br(256 * 64 * 8 * 2);
+                CK(hipMemcpyFromSymbol(br.data(), HIP_SYMBOL(rmx_stamps_bar), br.size() * 4));
+                double dr[8] = {0}, bw[8] = {0};
+                for (int wg = 0; wg < 256; ++wg) for (int k = 0; k + 1 < W / 256 && k + 1 < 64; ++k) for (int w8 = 0; w8 < 8; ++w8) {
+                    dr[w8] += br[((wg * 64 + k) * 8 + w8) * 2]; bw[w8] += br[((wg * 64 + k) * 8 + w8) * 2 + 1]; }
+                printf("    LDS drain before the barriers, ticks per window, waves 0..7:");
+                for (int w8 = 0; w8 < 8; ++w8) printf(" %.0f", dr[w8] / n);
+                printf("\n    waiting at the barriers, ticks per window, waves 0..7:        ");
+                for (int w8 = 0; w8 < 8; ++w8) printf(" %.0f", bw[w8] / n);
+                printf("\n");
                 printf("    stamps (s_memtime ticks, mean over %d windows): phase 1 %.0f  phase 2 %.0f  whole window %.0f\n", n, p1 / n, p2 / n, tot / n);
             }
 #endif
