@@ -135,7 +135,8 @@ __device__ __forceinline__ void resolve_batch(int lane, const float4* red, const
 // boundaries of every window it processes; no stamp exists in the product build
 __device__ long long rmx_stamps[256 * 64 * 4];
 __device__ int rmx_stamps_vm[256 * 64 * 8];
-__device__ int rmx_stamps_bar[256 * 64 * 8 * 2];   // per wave: ticks draining its LDS stores in front of the barriers / waiting at them   // per wave: ticks spent in the vmcnt wait at the head of h1, summed over the window's pairs
+__device__ int rmx_stamps_bar[256 * 64 * 8 * 2];
+__device__ int rmx_stamps_pc[256 * 64 * 8 * 2];    // per wave: ticks in the first / second piece between two barriers of the anchor loop   // per wave: ticks draining its LDS stores in front of the barriers / waiting at them   // per wave: ticks spent in the vmcnt wait at the head of h1, summed over the window's pairs
 #define RMX_STAMP(slot)                                                                              \
     do {                                                                                             \
         if (t == 0 && (wl / (int)gridDim.x) < 64)                                                    \
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
     int npair = 0;       // pair counter: selects the record slot (ring of kResSlots)
     int npend = 0;       // pairs whose records await a resolve
 #ifdef RMX_KWIN_STAMPS
-    int stamp_vm = 0, stamp_drain = 0, stamp_bar = 0;
+    int stamp_vm = 0, stamp_drain = 0, stamp_bar = 0, stamp_pc1 = 0, stamp_pc2 = 0;
 #endif
 
 
@@ -688,13 +689,57 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
             barrier_hook(false);
             const bool has_next = m + 1 < M2;
             const int out_idx = out_of(ci, j_of(ci, cs));
+#ifndef RMX_KWIN_PRIO_MODE
+#define RMX_KWIN_PRIO_MODE 1
+#endif
+#if !defined(RMX_KWIN_PRIO) && !defined(RMX_KWIN_NO_PRIO)
+#define RMX_KWIN_PRIO 1      /* default: on (-0.8 ... -1.0 % in three A/B runs, tools/probe/kwin_bench.hip) */
+#endif
+#ifdef RMX_KWIN_PRIO
+            // The two waves of a SIMD share its issue slots (and the CU's LDS / vector-memory request paths), and every
+            // arbiter prefers the OLDER one: in-kernel stamps (tools/probe/kwin_bench.hip -DRMX_KWIN_STAMPS) show waves 0-3
+            // spending 51-60 k ticks per window in the two pieces between barriers where waves 4-7 need 57-64 k, and then
+            // waiting ~950 ticks at every barrier for them (waves 4-7: ~270).  Priority outranks age, so waves 4-7 run the
+            // FIRST of their two pieces at priority 1 and the second at 0.  It only helps the piece that is VALU-bound (h2
+            // as first piece: 63.9 -> 58.1 k ticks; h1 does not react to priority), so the launch gains 0.8-1.0 %, not the 8 %
+            // an even split would give; priority during h2 only (mode 2) and priority 3 measured the same or less.
+#if RMX_KWIN_PRIO_MODE == 2   /* priority during h2 only (where it was seen to help), whichever piece that is */
+            if (wave >= 4) { if (late_h2) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(RMX_KWIN_PRIO); }
+#define RMX_PRIO_MID() do { if (wave >= 4) { if (late_h2) __builtin_amdgcn_s_setprio(RMX_KWIN_PRIO); else __builtin_amdgcn_s_setprio(0); } } while (0)
+#else
+            if (wave >= 4) __builtin_amdgcn_s_setprio(RMX_KWIN_PRIO);
+#define RMX_PRIO_MID() do { if (wave >= 4) __builtin_amdgcn_s_setprio(0); } while (0)
+#endif
+#else
+#define RMX_PRIO_MID() do { } while (0)
+#endif
+#ifdef RMX_KWIN_STAMPS
+            const long long p0 = __builtin_readcyclecounter();
+            long long p1;
+#define RMX_PIECE_MID() p1 = __builtin_readcyclecounter()
+#else
+#define RMX_PIECE_MID() do { } while (0)
+#endif
             if (late_h2) {
                 if (has_next) h1_of(ni, ns, seq + 1);
+                RMX_PRIO_MID();
+                RMX_PIECE_MID();
                 pair_h2(seq, out_idx);
             } else {
                 pair_h2(seq, out_idx);
+                RMX_PRIO_MID();
+                RMX_PIECE_MID();
                 if (has_next) h1_of(ni, ns, seq + 1);
             }
+#ifdef RMX_KWIN_STAMPS
+            {
+                const long long p2 = __builtin_readcyclecounter();
+                stamp_pc1 += (int)(p1 - p0);
+                stamp_pc2 += (int)(p2 - p1);
+            }
+#endif
+#undef RMX_PIECE_MID
+#undef RMX_PRIO_MID
             ++seq;
             ci = ni; cs = ns;
             ++ns;
@@ -707,6 +752,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
         rmx_stamps_vm[((int)blockIdx.x * 64 + wl / (int)gridDim.x) * 8 + wave] = stamp_vm;
         rmx_stamps_bar[(((int)blockIdx.x * 64 + wl / (int)gridDim.x) * 8 + wave) * 2] = stamp_drain;
         rmx_stamps_bar[(((int)blockIdx.x * 64 + wl / (int)gridDim.x) * 8 + wave) * 2 + 1] = stamp_bar;
+        rmx_stamps_pc[(((int)blockIdx.x * 64 + wl / (int)gridDim.x) * 8 + wave) * 2] = stamp_pc1;
+        rmx_stamps_pc[(((int)blockIdx.x * 64 + wl / (int)gridDim.x) * 8 + wave) * 2 + 1] = stamp_pc2;
     }
 #endif
     seq = 0;   // any wave may resolve the last pairs; take wave 0

@@ -55,6 +55,14 @@ static void launch_base(const Bufs& b, hipStream_t s) {
     hipLaunchKernelGGL(k_win<false>, dim3(256), dim3(kThreads), kLdsWinBytes, s, (const void*)b.iq, b.spec, b.tw1, b.tw2, b.B, 0L,
                        b.out_scale, b.li, b.lf, b.pk, b.W, 0, 1);
 }
+#define KWB_STAG(NAME, ST)                                                                                               \
+    static void NAME(const Bufs& b, hipStream_t s) {                                                                    \
+        hipLaunchKernelGGL(k_win<false>, dim3(256), dim3(kThreads), kLdsWinBytes, s, (const void*)b.iq, b.spec, b.tw1, b.tw2, \
+                           b.B, 0L, b.out_scale, b.li, b.lf, b.pk, b.W, 0, ST);                                        \
+    }
+KWB_STAG(launch_stag2, 2)
+KWB_STAG(launch_stag3, 3)
+KWB_STAG(launch_stag4, 4)
 static void launch_stag0(const Bufs& b, hipStream_t s) {
     hipLaunchKernelGGL(k_win<false>, dim3(256), dim3(kThreads), kLdsWinBytes, s, (const void*)b.iq, b.spec, b.tw1, b.tw2, b.B, 0L,
                        b.out_scale, b.li, b.lf, b.pk, b.W, 0, 0);
@@ -126,6 +134,11 @@ int main(int argc, char** argv) {
     std::vector<Variant> vars = {
         {"k_win stag=1 (production)", launch_base, (const void*)k_win<false>, kLdsWinBytes},
         {"k_win stag=0", launch_stag0, (const void*)k_win<false>, kLdsWinBytes},
+#ifdef KWB_ALL_STAGS
+        {"k_win stag=2 (odd waves late)", launch_stag2, (const void*)k_win<false>, kLdsWinBytes},
+        {"k_win stag=3 (waves 4-7 late)", launch_stag3, (const void*)k_win<false>, kLdsWinBytes},
+        {"k_win stag=4 (one of every SIMD, alternating)", launch_stag4, (const void*)k_win<false>, kLdsWinBytes},
+#endif
 #ifdef KWB_HAVE_KWIN2
         KWB_KWIN2_TABLE
 #endif
@@ -205,6 +218,16 @@ int main(int argc, char** argv) {
                 for (int w8 = 0; w8 < 8; ++w8) printf(" %.0f", dr[w8] / n);
                 printf("\n    waiting at the barriers, ticks per window, waves 0..7:        ");
                 for (int w8 = 0; w8 < 8; ++w8) printf(" %.0f", bw[w8] / n);
+                printf("\n");
+                std::vector<int> pc(256 * 64 * 8 * 2);
+                CK(hipMemcpyFromSymbol(pc.data(), HIP_SYMBOL(rmx_stamps_pc), pc.size() * 4));
+                double c1[8] = {0}, c2[8] = {0};
+                for (int wg = 0; wg < 256; ++wg) for (int k = 0; k + 1 < W / 256 && k + 1 < 64; ++k) for (int w8 = 0; w8 < 8; ++w8) {
+                    c1[w8] += pc[((wg * 64 + k) * 8 + w8) * 2]; c2[w8] += pc[((wg * 64 + k) * 8 + w8) * 2 + 1]; }
+                printf("    anchor loop, first piece of the interval, ticks per window, waves 0..7: ");
+                for (int w8 = 0; w8 < 8; ++w8) printf(" %.0f", c1[w8] / n);
+                printf("\n    anchor loop, second piece, ticks per window, waves 0..7:                ");
+                for (int w8 = 0; w8 < 8; ++w8) printf(" %.0f", c2[w8] / n);
                 printf("\n");
                 printf("    stamps (s_memtime ticks, mean over %d windows): phase 1 %.0f  phase 2 %.0f  whole window %.0f\n", n, p1 / n, p2 / n, tot / n);
             }
