@@ -30,6 +30,7 @@
 #include "win8.hpp"    // (radix-8 register blocks shared with generic_path.hpp; its kernel k_win8 is instantiated only under
 #include "winpk.hpp"   //  -DRMX_EXPERIMENTS, like k_winp: templates that nothing references cost nothing)
 #include "generic_path.hpp"
+#include "win_eo.hpp"
 #include "detect_path.hpp"
 
 namespace rmx {
@@ -647,6 +648,7 @@ struct rmx_ctx {
     int g_ws_thr = 0, g_ws_upw = 0, g_ws_grid = 0;
     float4* g_ws_scratch = nullptr;
     float2* g_tw_win = nullptr;            // W_L half table of that kernel
+    float2* g_tw_l = nullptr;              // g_win_eo15 (N = 16384): W_32768^i, i < 1024
     const void* g_cols_inv_fn = nullptr;
     const void* g_cols_fwd_fn[2] = {nullptr, nullptr};   // [u8]
     const void* g_rows_inv_fn = nullptr;
@@ -1018,18 +1020,30 @@ static int generic_init(rmx_ctx* c) {
     }
     // any buoy count, 512 <= L <= 16384: whole windows in one persistent kernel, spectra in a per-workgroup scratch
     // (RMX_WSCR=0: the two-kernel LDS path / the four-step path, which the Doppler search uses in any case)
-    c->g_wscr = !c->g_wfused && c->g_logL >= 9 && c->g_logL <= 14;
+    c->g_wscr = !c->g_wfused && c->g_logL >= 9 && c->g_logL <= 15;   // (15: the even / odd-bin halves, win_eo.hpp)
     { long v; if (c->knobs.get("wscr", &v)) {          // 0: never, 2: also for batches that do not fill the chip (tests)
         c->g_wscr = c->g_wscr && v != 0;
         c->g_wscr_always = v == 2;
     } }
     if (c->g_wscr) {
-        make_row_table(t, (int)L);
+        make_row_table(t, c->g_logL == 15 ? 16384 : (int)L);       // (N = 16384: two 16384-point halves)
         int rc = upload(c, &c->g_tw_win, t);
         if (rc) return rc;
         c->g_ws_fn[0] = wscr_fn<false>(c->g_logL);
         c->g_ws_fn[1] = wscr_fn<true>(c->g_logL);
         wscr_shape(c->g_logL, &c->g_ws_thr, &c->g_ws_upw, &c->g_ws_lds);
+        if (c->g_logL == 15) {
+            const double two_pi = 6.283185307179586476925286766559;
+            std::vector<float2> wl(1024);
+            for (int i = 0; i < 1024; ++i) wl[i] = make_float2((float)std::cos(two_pi * i / 32768.0), (float)-std::sin(two_pi * i / 32768.0));
+            rc = upload(c, &c->g_tw_l, wl);
+            if (rc) return rc;
+            c->g_ws_fn[0] = (const void*)gen::g_win_eo15<false>;
+            c->g_ws_fn[1] = (const void*)gen::g_win_eo15<true>;
+            c->g_ws_thr = 512;
+            c->g_ws_upw = 1;
+            c->g_ws_lds = gen::kWinEoLds;
+        }
         // L = 16384: 512 threads x two butterflies (g_win_scr14) unless RMX_WSCR14=0 (1024 threads x one: g_win_scr<14>)
         bool two = c->g_logL == 14;
         two = two && c->knobs.get_or("wscr14", 1) != 0;
@@ -1269,6 +1283,8 @@ static int generic_batch(rmx_ctx* c, const void* d_iq, int n_windows, int n_pair
     // without a workgroup are better off in the per-transform kernels below (8 buoys x 8 windows of 8192: 0.32 vs 0.05 ms).
     // Measured crossovers (tools/smallw.sh): 0.43 workgroups per CU at L = 16384 (8 buoys; 0.63 with 3), 0.66 .. 0.68 below
     const long ws_blocks = ((long)n_windows + (c->g_ws_upw > 0 ? c->g_ws_upw : 1) - 1) / (c->g_ws_upw > 0 ? c->g_ws_upw : 1);
+    // (L = 32768, g_win_eo15: it wins from about 0.7 workgroups per CU on for 2 ... 16 buoys -- 0.67-0.79 x the four-step's time
+    // at 256 windows, 0.85-0.94 x at 192, 0.9-1.25 x at 128: profiles/r03_weo_sweep.log)
     const bool use_wscr = c->g_wscr && (c->g_wscr_always || ws_blocks >= (c->g_logL == 14 ? 7L : 11L) * c->n_cus / 16);
     const bool whole_window = c->g_wfused || use_wscr;   // those kernels keep no per-window state in HBM
     int rc = generic_ensure(c, n_pairs, !whole_window, !whole_window);
@@ -1284,6 +1300,12 @@ static int generic_batch(rmx_ctx* c, const void* d_iq, int n_windows, int n_pair
         const gen::GPair* a_pairs = c->g_pairs;
         long grid = ((long)n_windows + c->g_ws_upw - 1) / c->g_ws_upw;
         if (grid > c->g_ws_grid) grid = c->g_ws_grid;
+        if (logL == 15) {                          // g_win_eo15: one more table
+            const float2* a_twl = c->g_tw_l;
+            void* args[] = {&a_iq, &a_scr, &a_tw, &a_twl, &a_nb, &a_nw, &a_first, &a_fs, &a_os, &a_pairs, &a_np, &d_lag, &d_frac, &d_peak};
+            RMX_HIP(c, hipLaunchKernel(c->g_ws_fn[u8 ? 1 : 0], dim3((unsigned)grid), dim3(c->g_ws_thr), args, c->g_ws_lds, c->stream));
+            return RMX_OK;
+        }
         void* args[] = {&a_iq, &a_scr, &a_tw, &a_nb, &a_nw, &a_first, &a_fs, &a_os, &a_pairs, &a_np, &d_lag, &d_frac, &d_peak};
         RMX_HIP(c, hipLaunchKernel(c->g_ws_fn[u8 ? 1 : 0], dim3((unsigned)grid), dim3(c->g_ws_thr), args, c->g_ws_lds, c->stream));
         return RMX_OK;
@@ -1443,7 +1465,7 @@ void rmx_destroy(rmx_ctx* c) {
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     for (void* p : {(void*)c->g_tw, (void*)c->g_tw1, (void*)c->g_tw2, (void*)c->g_thi, (void*)c->g_tlo, (void*)c->g_spec,
                     (void*)c->g_spec_r, (void*)c->g_prod, (void*)c->g_rec, (void*)c->g_halo, (void*)c->g_pairs,
-                    (void*)c->g_ws_scratch, (void*)c->g_tw_win})
+                    (void*)c->g_ws_scratch, (void*)c->g_tw_win, (void*)c->g_tw_l})
         if (p) (void)hipFree(p);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     for (hipEvent_t e : c->copy_ev)

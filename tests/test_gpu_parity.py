@@ -679,15 +679,19 @@ def test_whole_window_kernel_by_length(xc, N, B, opts):
     assert np.array_equal(ui, li) and np.all(np.abs(uf - lf) <= TOL) and np.allclose(up, pk, rtol=1e-5)
 
 
-@pytest.mark.parametrize("N,B", [(256, 5), (512, 8), (1024, 6), (2048, 8), (2048, 16), (8192, 3), (8192, 8), (8192, 2), (8192, 4)])
+@pytest.mark.parametrize("N,B", [(256, 5), (512, 8), (1024, 6), (2048, 8), (2048, 16), (8192, 3), (8192, 8), (8192, 2), (8192, 4),
+                                 (16384, 2), (16384, 3), (16384, 8), (16384, 5)])
 def test_whole_window_scratch_kernel_by_length(xc, N, B, opts):
     """Every other shape with 512 <= L <= 16384 -- more than four buoys, or N = 8192 (the capture length of
     iq_stream_client.py:459) -- runs whole windows in one persistent kernel with the spectra in a per-workgroup
     scratch (g_win_scr, compiled per length; at L = 16384 one 136 KiB transform per CU, 1024 threads): against the
     oracle on complex64 and raw uint8 input, more windows than one pass of the grid on the small lengths, a custom
     pair list (reversed, repeated, autocorrelation), and the previous path (RMX_WSCR=0: two-kernel LDS path or
-    four-step) on the same input."""
-    W = 700 if N <= 512 else ((530 if B == 4 else 5) if N >= 8192 else 9)    # (530: every persistent workgroup takes several windows)
+    four-step) on the same input.
+    N = 16384 (the capture length of buoy_node.py:364; L = 32768 does not fit the LDS): g_win_eo15 (win_eo.hpp) -- the
+    even-bin and odd-bin halves as two LDS-resident 16384-point transforms, the even half's result kept in registers
+    -- with 2, 3, 5 and 8 buoys; 5 buoys with more windows than workgroups (persistent loop, scratch reuse)."""
+    W = 700 if N <= 512 else ((530 if B == 4 else 5) if N == 8192 else (300 if (N, B) == (16384, 5) else (4 if N == 16384 else 9)))    # (530 / 300: every persistent workgroup takes several windows)
     iq, _, raw = rm.synth.make_windows(W, B, N, 2.4e6, seed=800 + B + N % 977, return_u8=True)
     sub = slice(0, min(W, 12))                                   # literal oracle on the first windows, the rest by consistency
     ri, rf, rp = orc.xcorr_batch_literal(iq[sub])
