@@ -136,6 +136,7 @@ __device__ __forceinline__ void resolve_batch(int lane, const float4* red, const
 __device__ long long rmx_stamps[256 * 64 * 4];
 __device__ int rmx_stamps_vm[256 * 64 * 8];
 __device__ int rmx_stamps_bar[256 * 64 * 8 * 2];
+__device__ int rmx_stamps_p1[256 * 64 * 8 * 8];   // per wave: ticks of phase 1 by piece (RMX_LAP buckets)
 __device__ int rmx_stamps_pc[256 * 64 * 8 * 2];    // per wave: ticks in the first / second piece between two barriers of the anchor loop   // per wave: ticks draining its LDS stores in front of the barriers / waiting at them   // per wave: ticks spent in the vmcnt wait at the head of h1, summed over the window's pairs
 #define RMX_STAMP(slot)                                                                              \
     do {                                                                                             \
@@ -228,6 +229,14 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
     int npend = 0;       // pairs whose records await a resolve
 #ifdef RMX_KWIN_STAMPS
     int stamp_vm = 0, stamp_drain = 0, stamp_bar = 0, stamp_pc1 = 0, stamp_pc2 = 0;
+    int lap_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long lap_last = __builtin_readcyclecounter();
+    bool lap_on = true;
+    // lap timer of phase 1: the time since the previous lap goes to bucket k (0 forward role A, 1 its barrier, 2 roles B + C,
+    // 3 spectrum store, 4 h1, 5 the pair's barrier, 6 h2)
+#define RMX_LAP(k) do { if (lap_on) { const long long c_ = __builtin_readcyclecounter(); lap_acc[k] += (int)(c_ - lap_last); lap_last = c_; } } while (0)
+#else
+#define RMX_LAP(k) do { } while (0)
 #endif
 
 
@@ -308,14 +317,19 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
 #else
         constexpr int Q0 = 4 * G, Q1 = 4 * G + 4;
 #endif
+        // (the buoy's byte offset is made opaque HERE so that each request's SGPR offset is one s_add in front of it:
+        // left to itself hipcc precomputes all of them ahead of the loop, runs out of SGPRs, and every request then
+        // pays v_readlane + s_nop 4 to get its offset back out of a spill lane)
+        int bo = b * (kM * samp_bytes);
+        asm volatile("" : "+s"(bo));
         if constexpr (U8) {
 #pragma unroll
             for (int q = Q0; q < Q1; ++q)
-                d.re[q] = __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs, xoff, (b * kM + q * 256) * 2, 0));
+                d.re[q] = __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs, xoff, bo + q * 256 * 2, 0));
         } else {
 #pragma unroll
             for (int q = Q0; q < Q1; ++q) {
-                const u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(rs, xoff, (b * kM + q * 256) * 8, 0);
+                const u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(rs, xoff, bo + q * 256 * 8, 0);
                 d.set(q, __uint_as_float(r.x), __uint_as_float(r.y));
             }
         }
@@ -339,9 +353,11 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
 #else
         constexpr int J0 = 2 * G, J1 = 2 * G + 2;
 #endif
+        int bo = b * (8 * kThreads * 16);   // (opaque: see load_x_part_from)
+        asm volatile("" : "+s"(bo));
 #pragma unroll
         for (int j = J0; j < J1; ++j) {
-            const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(ss, soff, (b * 8 + j) * (kThreads * 16), 0);
+            const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(ss, soff, bo + j * (kThreads * 16), 0);
             d.set(2 * j, __uint_as_float(w.x), __uint_as_float(w.y));
             d.set(2 * j + 1, __uint_as_float(w.z), __uint_as_float(w.w));
         }
@@ -371,6 +387,11 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
     auto fwd = [&](C16& xc) __attribute__((always_inline)) {
         float2* img = (seq & 1) ? img1 : img0;
         float2 x[16];
+#ifdef RMX_KWIN_STAMPS
+        RMX_LAP(6);                                       // (cvt_x and whatever else sits between h2 and here)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // bucket 7: waiting for the window samples (and the spectrum stores)
+        RMX_LAP(7);
+#endif
 #pragma unroll
         for (int q = 0; q < 16; ++q) x[q] = xc.get(q);
         mul_w32_odd(x);            // odd sub-transform input x*W32^q (W_L^u is folded into tw1)
@@ -378,7 +399,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
         mul_tw1(x, tw1);
 #ifndef RMX_KWIN_LDS1
         if (!(dbg & 8)) xchg_a2_write(img, x, t);
+        RMX_LAP(0);
         barrier_hook(false);
+        RMX_LAP(1);
         if (!(dbg & 8)) xchg_b2_read(img, x, t);
 #else
         if (!(dbg & 8)) xchg_a_write(img, x, t);
@@ -408,6 +431,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
 #pragma unroll
         for (int q = 0; q < 16; ++q) xc.set(q, x[q].x, x[q].y);   // (scaled by 2^-6 through the TW1 table)
         ++seq;
+        RMX_LAP(2);
     };
     // One pair = two halves around its only workgroup barrier.
     //   h1  conj-multiply merged into the role-C pass, wave-local exchange, role-B pass, stores into
@@ -620,8 +644,11 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
     };
     auto pair = [&](const C16& a, const C16& s, int out_idx, auto prefetch) __attribute__((always_inline)) {
         pair_h1(a, s, seq, prefetch);
+        RMX_LAP(4);
         barrier_hook(false);                     // the pair's only barrier
+        RMX_LAP(5);
         pair_h2(seq, out_idx);
+        RMX_LAP(6);
         ++seq;
     };
     auto out_of = [&](int i, int j) -> int { return i * B - (i * (i + 1)) / 2 + (j - i - 1); };
@@ -640,12 +667,14 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
         cvt_x(sb);
         fwd(sb);
         store_spec(sb, e);
+        RMX_LAP(3);
         pair(sa, sb, out_of(0, e), [&](auto part) __attribute__((always_inline)) { load_x_part(sb, e + 1, part); });
     }
     if (B > 1) {
         cvt_x(sb);
         fwd(sb);
         store_spec(sb, B - 1);
+        RMX_LAP(3);
         pair(sa, sb, out_of(0, B - 1), [&](auto part) __attribute__((always_inline)) {
             if (B > 2) {               // next anchor 1 streams downwards from B-1: X_{B-1} is L2-hot
                 load_spec_part(sa, 1, part);
@@ -654,6 +683,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
         });
     }
     RMX_STAMP(1);
+#ifdef RMX_KWIN_STAMPS
+    lap_on = false;
+#endif
     // ---- anchors 1..B-2: the stream direction alternates (odd anchors walk j down, even ones up), so
     // the first spectra an anchor streams are the ones the previous anchor touched last (L2 hits).
     // Between two barriers sit h2 of pair m and h1 of pair m+1, which are independent: waves 0-3 run
@@ -752,6 +784,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
         rmx_stamps_vm[((int)blockIdx.x * 64 + wl / (int)gridDim.x) * 8 + wave] = stamp_vm;
         rmx_stamps_bar[(((int)blockIdx.x * 64 + wl / (int)gridDim.x) * 8 + wave) * 2] = stamp_drain;
         rmx_stamps_bar[(((int)blockIdx.x * 64 + wl / (int)gridDim.x) * 8 + wave) * 2 + 1] = stamp_bar;
+        for (int k = 0; k < 8; ++k) rmx_stamps_p1[(((int)blockIdx.x * 64 + wl / (int)gridDim.x) * 8 + wave) * 8 + k] = lap_acc[k];
         rmx_stamps_pc[(((int)blockIdx.x * 64 + wl / (int)gridDim.x) * 8 + wave) * 2] = stamp_pc1;
         rmx_stamps_pc[(((int)blockIdx.x * 64 + wl / (int)gridDim.x) * 8 + wave) * 2 + 1] = stamp_pc2;
     }

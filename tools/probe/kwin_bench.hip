@@ -229,6 +229,18 @@ int main(int argc, char** argv) {
                 printf("\n    anchor loop, second piece, ticks per window, waves 0..7:                ");
                 for (int w8 = 0; w8 < 8; ++w8) printf(" %.0f", c2[w8] / n);
                 printf("\n");
+                std::vector<int> l1(256 * 64 * 8 * 8);
+                CK(hipMemcpyFromSymbol(l1.data(), HIP_SYMBOL(rmx_stamps_p1), l1.size() * 4));
+                static const char* lapname[8] = {"forward role A (+ load wait, cvt)", "forward barrier", "forward roles B + C", "spectrum store",
+                                                 "h1 of (0, e)", "pair barrier", "h2 of (0, e)", "vmcnt wait at the head of forward"};
+                for (int k7 = 0; k7 < 8; ++k7) {
+                    double a8[8] = {0};
+                    for (int wg = 0; wg < 256; ++wg) for (int k = 0; k + 1 < W / 256 && k + 1 < 64; ++k) for (int w8 = 0; w8 < 8; ++w8)
+                        a8[w8] += l1[((wg * 64 + k) * 8 + w8) * 8 + k7];
+                    printf("    phase 1, %-34s ticks per window, waves 0..7:", lapname[k7]);
+                    for (int w8 = 0; w8 < 8; ++w8) printf(" %.0f", a8[w8] / n);
+                    printf("\n");
+                }
                 printf("    stamps (s_memtime ticks, mean over %d windows): phase 1 %.0f  phase 2 %.0f  whole window %.0f\n", n, p1 / n, p2 / n, tot / n);
             }
 #endif
