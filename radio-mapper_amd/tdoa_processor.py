@@ -203,6 +203,10 @@ class TDoACalculator:
         s = det.iq_samples
         if s is None or det.sample_rate_hz is None:
             return None
+        if isinstance(s, (list, tuple)) and len(s) and isinstance(s[0], (str, list, tuple)):
+            # the reference's wire form: NumpyEncoder turns every complex into str(obj) (iq_stream_client.py:31-44)
+            from .iq_wire import parse_complex_list
+            return parse_complex_list(s)
         a = np.asarray(s)
         if a.dtype == np.uint8:
             return a
@@ -211,7 +215,11 @@ class TDoACalculator:
     def _iq_batch_key(self, detections: Sequence[SignalDetection]):
         """(key, stacked [B][N] windows) when every detection of the group carries an IQ window of one
         shape, dtype and sample rate; (None, None) when none does; (False, None) when they disagree."""
-        iqs = [self._iq_of(d) for d in detections]
+        try:
+            iqs = [self._iq_of(d) for d in detections]
+        except ValueError as e:      # wire data that does not parse (iq_wire.IqWireError): logged, no measurements
+            self.logger.error(f"IQ samples of the group cannot be decoded: {e}")
+            return False, None
         if all(a is None for a in iqs):
             return None, None
         # IQ was supplied for this group: from here on the time tags alone are never used for it.  A group that

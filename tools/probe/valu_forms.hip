@@ -68,6 +68,10 @@ __global__ __launch_bounds__(1024) void k(float* out, int iters, float bb, float
                     else if (MODE == 33) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
                     else if (MODE == 34) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
                     else if (MODE == 35) asm volatile("v_fmamk_f32 %0, %0, 0x3f3504f3, %1" : "+v"(a[i]) : "v"(c));
+                    else if (MODE == 36) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a[i]), "+v"(a[(i + 4) & 7]));
+                    else if (MODE == 37) asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(a[i]), "+v"(a[(i + 4) & 7]));
+                    else if (MODE == 38) asm volatile("v_add_f32_dpp %0, %1, %0 row_mirror row_mask:0xf bank_mask:0xf" : "+v"(a[i]) : "v"(c));
+                    else if (MODE == 39) asm volatile("v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(a[i]) : "v"(c));
                 }
                 if (MODE >= 40 && MODE < 50) {   // every second instruction
                     if ((i & 1) != 0) asm volatile("v_add_f32_e32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
@@ -149,6 +153,10 @@ int main() {
     run<33>("1/4 v_max3_f32");
     run<34>("1/4 v_fma_f32 v, v, v");
     run<35>("1/4 v_fmamk_f32 literal");
+    run<36>("1/4 v_permlane32_swap_b32");
+    run<37>("1/4 v_permlane16_swap_b32");
+    run<38>("1/4 v_add_f32_dpp row_mirror");
+    run<39>("1/4 v_mov_b32_dpp quad_perm");
     std::printf("(one in two)\n");
     run<40>("1/2 v_mul_f32 v, s, v");
     run<41>("1/2 v_fmac_f32_dpp");
