@@ -317,9 +317,11 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
 #else
         constexpr int Q0 = 4 * G, Q1 = 4 * G + 4;
 #endif
-        // (the buoy's byte offset is made opaque HERE so that each request's SGPR offset is one s_add in front of it:
-        // left to itself hipcc precomputes all of them ahead of the loop, runs out of SGPRs, and every request then
-        // pays v_readlane + s_nop 4 to get its offset back out of a spill lane)
+        // (the buoy's byte offset is made opaque HERE so that each request's SGPR offset is computed in front of it (s_mov +
+        // s_addk): left to itself hipcc precomputes all of them ahead of the loop, runs out of SGPRs, and every request
+        // then pays v_readlane + s_nop 4 to get its offset back out of a spill lane.  One `s_add_i32` per request in a
+        // volatile asm is one instruction fewer and measured +1.5 %: volatile statements keep their order among
+        // themselves, which pins every request between the exchange stores around it.)
         int bo = b * (kM * samp_bytes);
         asm volatile("" : "+s"(bo));
         if constexpr (U8) {
@@ -707,14 +709,38 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
             int pi = hi, ps = hs + 1;
             if (ps >= B - 1 - pi) { ++pi; ps = 0; }
             const bool valid = pi + 1 < B;
-            const bool new_anchor = pi != hi;
+            const bool new_anchor = valid && pi != hi;
+#ifndef RMX_KWIN_REQ_BRANCHY
+            // Every instruction costs the issuing wave ~2 ns whatever its kind (tools/probe/valu_forms.hip), and the two
+            // uniform branches around each of the eight requests were 45 scalar instructions per pair plus the vector
+            // instructions hipcc used to carry their conditions: the streamed spectrum is now requested unconditionally
+            // (behind the window's last pair an index that exists: the registers are dead there), and a new anchor's
+            // eight requests go out together behind ONE branch, in the first callback (6 of a window's 21 pairs).
+            const int pj = valid ? j_of(pi, ps) : B - 1;
+            pair_h1(sa, sb, tr, [&](auto part) __attribute__((always_inline)) {
+                if constexpr (decltype(part)::value == 0) {
+                    if (new_anchor) {
+                        load_spec_part(sa, pi, std::integral_constant<int, 0>{});
+                        load_spec_part(sa, pi, std::integral_constant<int, 1>{});
+                        load_spec_part(sa, pi, std::integral_constant<int, 2>{});
+                        load_spec_part(sa, pi, std::integral_constant<int, 3>{});
+                        load_spec_part(sa, pi, std::integral_constant<int, 4>{});
+                        load_spec_part(sa, pi, std::integral_constant<int, 5>{});
+                        load_spec_part(sa, pi, std::integral_constant<int, 6>{});
+                        load_spec_part(sa, pi, std::integral_constant<int, 7>{});
+                    }
+                }
+                load_spec_part(sb, pj, part);
+            });
+#else
             const int pj = j_of(pi, ps);
             pair_h1(sa, sb, tr, [&](auto part) __attribute__((always_inline)) {
                 if (valid) {
-                    if (new_anchor) load_spec_part(sa, pi, part);
+                    if (pi != hi) load_spec_part(sa, pi, part);
                     load_spec_part(sb, pj, part);
                 }
             });
+#endif
         };
         if (M2 > 0) h1_of(ci, cs, seq);
         for (int m = 0; m < M2; ++m) {

@@ -20,11 +20,17 @@ __global__ __launch_bounds__(1024) void k(float* out, int iters, float bb, float
     unsigned long long m = threadIdx.x & 1 ? ~0ull : 0x5555555555555555ull;
     m = __builtin_amdgcn_readfirstlane((int)m) | ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(m >> 32)) << 32);
     typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const unsigned lds_addr8 = threadIdx.x * 8, lds_addr16 = threadIdx.x * 16, lds_addr4 = threadIdx.x * 4;
+    const int m0v = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) * 256);
+    f4 q4 = {b, c, b, c};
+    int sacc = 0;
     float a[8];
     f2 pa[8], pb = {b, b}, pc = {c, c};
 #pragma unroll
     for (int i = 0; i < 8; ++i) { a[i] = threadIdx.x + i; pa[i] = f2{a[i], a[i] + 1}; }
     for (int it = 0; it < iters; ++it) {
+        if (MODE >= 50 && MODE < 70) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
 #pragma unroll
@@ -81,6 +87,19 @@ __global__ __launch_bounds__(1024) void k(float* out, int iters, float bb, float
                     else if (MODE == 43) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
                     else if (MODE == 44) asm volatile("v_fmamk_f32 %0, %0, 0x3f3504f3, %1" : "+v"(a[i]) : "v"(c));
                 }
+                if (MODE >= 50 && MODE < 70) {   // one non-VALU instruction among seven v_add_f32_e32
+                    if ((i & 7) != 0) asm volatile("v_add_f32_e32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
+                    else if (MODE == 50) asm volatile("ds_write_b64 %0, %1 offset:0" : : "v"(lds_addr8), "v"(pa[r & 7]) : "memory");
+                    else if (MODE == 51) asm volatile("ds_write_b128 %0, %1 offset:0" : : "v"(lds_addr16), "v"(q4) : "memory");
+                    else if (MODE == 52) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tds_write_addtid_b32 %0 offset:0" : : "v"(a[1]), "s"(m0v) : "memory");
+                    else if (MODE == 53) asm volatile("ds_read_b64 %0, %1 offset:0" : "=v"(pa[r & 7]) : "v"(lds_addr8) : "memory");
+                    else if (MODE == 54) asm volatile("ds_read_b128 %0, %1 offset:0" : "=v"(q4) : "v"(lds_addr16) : "memory");
+                    else if (MODE == 55) asm volatile("s_add_u32 %0, %0, 3" : "+s"(sacc) : : "scc");
+                    else if (MODE == 56) asm volatile("s_nop 0");
+                    else if (MODE == 57) asm volatile("ds_write_b32 %0, %1 offset:0" : : "v"(lds_addr4), "v"(a[1]) : "memory");
+                    else if (MODE == 58) asm volatile("s_waitcnt lgkmcnt(15)");
+                    else if (MODE == 59) asm volatile("v_add_f32_e32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
+                }
                 if (MODE == 26) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(pa[i]) : "v"(pb), "v"(pc));
                 if (MODE == 27) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(pa[i]) : "v"(pb));
             }
@@ -89,6 +108,8 @@ __global__ __launch_bounds__(1024) void k(float* out, int iters, float bb, float
     float s = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) s += a[i] + pa[i].x + pa[i].y;
+    s += q4.x + q4.y + q4.z + q4.w + (float)sacc;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     out[blockIdx.x * 1024 + threadIdx.x] = s + sc;
 }
 
@@ -163,6 +184,17 @@ int main() {
     run<42>("1/2 v_cmp_eq_f32_e64 -> SGPR");
     run<43>("1/2 v_fma_f32 v, v, v");
     run<44>("1/2 v_fmamk_f32 literal");
+    std::printf("(one in EIGHT instructions of the named form, the rest v_add_f32_e32: ns per instruction slot)\n");
+    run<59>("1/8 v_add_f32_e32 (all VALU)");
+    run<55>("1/8 s_add_u32");
+    run<56>("1/8 s_nop 0");
+    run<58>("1/8 s_waitcnt lgkmcnt(15)");
+    run<57>("1/8 ds_write_b32");
+    run<50>("1/8 ds_write_b64");
+    run<51>("1/8 ds_write_b128");
+    run<52>("1/8 s_mov m0 + s_nop + ds_write_addtid_b32");
+    run<53>("1/8 ds_read_b64");
+    run<54>("1/8 ds_read_b128");
     std::printf("(packed: two results per instruction)\n");
     run<26>("v_pk_fma_f32");
     run<27>("v_pk_mul_f32");
