@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""Parity soak on the GPU box: random shapes, seeds, input types and pair lists through the C ABI against the oracle.
+
+    python tools/soak_parity.py [--seconds 240] [--seed 0] > gpurun_out/soak.txt
+
+Every case draws (N, B, W, input type, default or custom pair list, noise level) from the ranges the kernels dispatch
+on -- the fused N = 4096 kernel and its custom-pair-list kernels, the whole-window kernels (N = 256 ... 16 384), the
+LDS two-kernel path, the four-step path -- runs `XcorrEngine.correlate`, and compares with `oracle.xcorr_batch_fast`
+(the oracle is the checker here, never the thing measured): integer lag bit-exact, lag within 1e-5 * max(|lag|, 1),
+peak within 1e-5 relative.  An integer mismatch is excused only as in tests/test_gpu_parity.py: the oracle's two largest
+magnitudes are within 1e-5 relative AND the GPU picked the oracle's second candidate.  Prints one line per case and a
+summary; exit code 1 on any unexcused mismatch.  Progress goes to stdout at least every few seconds.
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+TOL = 1e-5
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=240.0)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--max-bytes", type=float, default=3.0e8, help="largest input batch in bytes (complex64)")
+    args = ap.parse_args()
+
+    import __graft_entry__ as g
+    g.build()
+    import radio_mapper_amd as rm
+    from radio_mapper_amd import xcorr
+    from oracle import xcorr_ref as orc
+
+    assert xcorr.device_count() > 0, "no GPU visible"
+    rng = np.random.default_rng(args.seed)
+    t_end = time.time() + args.seconds
+    n_cases = n_pw = n_excused = n_bad = 0
+    worst_lag = worst_peak = 0.0
+    by_n = {}
+    case = 0
+    while time.time() < t_end:
+        case += 1
+        # window length: weight the lengths with dedicated kernels
+        logn = int(rng.choice([4, 5, 6, 7, 8, 9, 10, 11, 12, 12, 12, 13, 13, 14, 14, 15, 16, 17, 18]))
+        N = 1 << logn
+        B = int(rng.choice([2, 3, 3, 4, 5, 6, 8, 8, 9, 12, 16])) if logn <= 14 else int(rng.choice([2, 3, 4, 6, 8]))
+        per_win = B * N * 8
+        w_max = max(1, int(args.max_bytes // per_win))
+        W = int(min(w_max, rng.choice([1, 2, 3, 7, 16, 61, 256, 300, 1024])))
+        u8 = bool(rng.integers(0, 2))
+        snr = float(rng.choice([10.0, 10.0, 3.0, 0.0, 20.0]))
+        fs = float(rng.choice([2.4e6, 10e6, 20e6]))
+        P_all = B * (B - 1) // 2
+        custom = bool(rng.integers(0, 3) == 0)
+        pairs = None
+        if custom:
+            k = int(rng.integers(1, P_all + 3))
+            ij = rng.integers(0, B, size=(k, 2))
+            ij[ij[:, 0] == ij[:, 1], 1] = (ij[ij[:, 0] == ij[:, 1], 0] + 1) % B      # i != j, any order, repeats allowed
+            pairs = np.ascontiguousarray(ij, dtype=np.int32)
+        seed = int(rng.integers(1, 2 ** 31 - 1))
+        out = rm.synth.make_windows(W, B, N, fs, seed=seed, snr_db=snr, return_u8=u8)
+        iq, raw = (out[0], out[2]) if u8 else (out[0], None)
+        t0 = time.time()
+        eng = xcorr.XcorrEngine(B, N, W)
+        try:
+            li, lf, pk = eng.correlate(raw if u8 else iq, pairs)
+        finally:
+            eng.close()
+        t_gpu = time.time() - t0
+        ri, rf, rp = orc.xcorr_batch_fast(iq, pairs, workers=8)
+        bad = li != ri
+        excused = np.zeros_like(bad)
+        if bad.any():
+            plist = orc.pair_list(B) if pairs is None else pairs
+            for w, q in zip(*np.nonzero(bad)):
+                i, j = int(plist[q, 0]), int(plist[q, 1])
+                margin, _, second = orc.peak_top2(iq[w, i], iq[w, j])
+                excused[w, q] = margin <= TOL and li[w, q] == second
+        ok = ~bad
+        ref = ri + rf
+        got = li + lf.astype(np.float64)
+        lag_err = np.max(np.abs(got - ref)[ok] / np.maximum(np.abs(ref[ok]), 1.0)) if ok.any() else 0.0
+        peak_err = np.max(np.abs(pk[ok] - rp[ok]) / np.maximum(np.abs(rp[ok]), 1e-30)) if ok.any() else 0.0
+        unexcused = int(np.sum(bad & ~excused))
+        tol_fail = int(lag_err > TOL) + int(peak_err > TOL)
+        n_cases += 1
+        n_pw += li.size
+        n_excused += int(excused.sum())
+        n_bad += unexcused + tol_fail
+        worst_lag = max(worst_lag, float(lag_err))
+        worst_peak = max(worst_peak, float(peak_err))
+        by_n[N] = by_n.get(N, 0) + li.size
+        print(f"case {case:4d}  N={N:7d} B={B:2d} W={W:5d} {'u8 ' if u8 else 'c64'} snr={snr:4.1f} "
+              f"pairs={'all' if pairs is None else len(pairs):>4} seed={seed:10d}  pair-windows={li.size:7d} "
+              f"int-mismatch={int(bad.sum())} (excused {int(excused.sum())})  lag_err={lag_err:.2e} peak_err={peak_err:.2e} "
+              f"gpu={t_gpu * 1e3:7.1f} ms{'  FAIL' if unexcused or tol_fail else ''}", flush=True)
+    print(f"SUMMARY: {n_cases} cases, {n_pw} pair-windows, {n_bad} failures, {n_excused} excused near-ties, "
+          f"worst relative lag error {worst_lag:.2e}, worst relative peak error {worst_peak:.2e}")
+    print("pair-windows per window length: " + ", ".join(f"{n}: {c}" for n, c in sorted(by_n.items())))
+    return 1 if n_bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
