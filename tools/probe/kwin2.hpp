@@ -18,7 +18,7 @@
 // pair code per half order, as in k_win.  tools/model_kwin2_schedule.py executes this schedule symbolically for
 // B = 2 ... 32 (every pair once, from the right registers, nothing overwritten while still needed).
 #pragma once
-#include "kwin.hpp"
+#include "../../radio-mapper_amd/csrc/kwin.hpp"
 
 namespace rmx {
 

@@ -15,8 +15,8 @@
 #include <vector>
 
 #include "../../radio-mapper_amd/csrc/kwin.hpp"
-#if __has_include("../../radio-mapper_amd/csrc/kwin2.hpp") && !defined(KWB_NO_KWIN2)
-#include "../../radio-mapper_amd/csrc/kwin2.hpp"
+#if !defined(KWB_NO_KWIN2)
+#include "kwin2.hpp"
 #define KWB_HAVE_KWIN2 1
 #endif
 
