@@ -58,3 +58,39 @@ def test_no_wide_store_with_sgpr_soffset_is_followed_by_a_write_to_its_data(tmp_
     assert n_wide > 0, "the disassembly shows no wide buffer store at all: the parser is out of date"
     assert not bad, "store-data hazard pattern: %s" % bad[:3]
     print("wide buffer stores: %d, with an SGPR soffset: %d, hazard patterns: 0" % (n_wide, n_sgpr))
+
+
+READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+
+
+@pytest.mark.skipif(not (os.path.exists(OBJDUMP) and os.path.exists(READELF)), reason="no llvm-objdump / llvm-readelf")
+def test_fused_kernel_keeps_its_registers_and_uses_no_scratch(tmp_path):
+    """Resource guard for the dominant kernel: k_win (both input types) runs two waves per SIMD with every array in
+    registers.  A code or compiler change that pushes it into scratch memory (a scratch access waits on vmcnt and drains
+    the spectra requested a pair ahead: DESIGN.md section 5.1) or past 256 VGPRs shows up here, not as a slower bench."""
+    import __graft_entry__ as g
+    g.build()
+    lib = os.path.join(ROOT, "radio-mapper_amd", "csrc", "librmx_hip.so")
+    work = str(tmp_path)
+    shutil.copy(lib, os.path.join(work, "lib.so"))
+    subprocess.run([OBJDUMP, "--offloading", "lib.so"], cwd=work, check=True, capture_output=True)
+    objs = [f for f in os.listdir(work) if "gfx950" in f]
+    assert objs
+    notes = subprocess.run([READELF, "--notes", objs[0]], cwd=work, check=True, capture_output=True, text=True).stdout
+    # the AMDGPU metadata note is YAML: one "- .agpr_count: ..." block per kernel
+    blocks = re.split(r"\n\s*- \.agpr_count:", notes)
+    seen = {}
+    for b in blocks[1:]:
+        name = re.search(r"\.name:\s+(\S+)", b)
+        if not name or "k_winILb" not in name.group(1):
+            continue
+        f = {k: int(re.search(r"\.%s:\s+(\d+)" % k, b).group(1)) for k in
+             ("private_segment_fixed_size", "vgpr_count", "vgpr_spill_count", "max_flat_workgroup_size")}
+        seen[name.group(1)] = f
+    assert len(seen) == 2, "expected k_win<false> and k_win<true> in the code object, found %s" % list(seen)
+    for n, f in seen.items():
+        assert f["private_segment_fixed_size"] == 0, (n, f)
+        assert f["vgpr_spill_count"] == 0, (n, f)
+        assert f["vgpr_count"] <= 256, (n, f)        # two waves per SIMD of the 512-register file
+        assert f["max_flat_workgroup_size"] == 512, (n, f)
+    print(seen)
