@@ -8,8 +8,10 @@ on -- the fused N = 4096 kernel and its custom-pair-list kernels, the whole-wind
 LDS two-kernel path, the four-step path -- runs `XcorrEngine.correlate`, and compares with `oracle.xcorr_batch_fast`
 (the oracle is the checker here, never the thing measured): integer lag bit-exact, lag within 1e-5 * max(|lag|, 1),
 peak within 1e-5 relative.  An integer mismatch is excused only as in tests/test_gpu_parity.py: the oracle's two largest
-magnitudes are within 1e-5 relative AND the GPU picked the oracle's second candidate.  Prints one line per case and a
-summary; exit code 1 on any unexcused mismatch.  Progress goes to stdout at least every few seconds.
+magnitudes are within 1e-5 relative AND the GPU picked the oracle's second candidate.  A lag beyond 1e-5 is excused
+only where the parabola is that ill-conditioned by itself: within four times what ONE float32 ulp on each of the oracle's
+own three taps moves its result (a flat peak on a short, noisy window).  Prints one line per case and a summary; exit
+code 1 on any unexcused mismatch.  Progress goes to stdout at least every few seconds.
 """
 import argparse
 import os
@@ -21,6 +23,26 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 TOL = 1e-5
+
+
+def parabola_ulp_bound(orc, x_i, x_j):
+    """How far one float32 ulp on each of the three taps moves the interpolated lag, relative to max(|lag|, 1): the part
+    of a lag difference that two correct float32 transforms cannot avoid (a flat peak: a - 2b + c small against b)."""
+    m = np.abs(orc.xcorr_full_scipy(x_i, x_j)).astype(np.float32)
+    n = x_i.shape[-1]
+    k = int(np.argmax(m))
+    if k == 0 or k == 2 * n - 2:
+        return 0.0
+    a, b, c = (float(v) for v in m[k - 1:k + 2])
+    den = a - 2.0 * b + c
+    if den == 0.0:
+        return 0.0
+    ulp = float(np.spacing(np.float32(b)))
+    pa = 0.5 * (1.0 / den - (a - c) / den ** 2)
+    pb = (a - c) / den ** 2
+    pc = 0.5 * (-1.0 / den - (a - c) / den ** 2)
+    lag = (k - (n - 1)) + 0.5 * (a - c) / den
+    return (abs(pa) + abs(pb) + abs(pc)) * ulp / max(abs(lag), 1.0)
 
 
 def soak_caf(args, rng, t_end, rm, xcorr, orc):
@@ -99,7 +121,7 @@ def main():
     t_end = time.time() + args.seconds
     if args.caf:
         return soak_caf(args, rng, t_end, rm, xcorr, orc)
-    n_cases = n_pw = n_excused = n_bad = 0
+    n_cases = n_pw = n_excused = n_bad = n_ill = 0
     worst_lag = worst_peak = 0.0
     by_n = {}
     case = 0
@@ -145,10 +167,24 @@ def main():
         ok = ~bad
         ref = ri + rf
         got = li + lf.astype(np.float64)
-        lag_err = np.max(np.abs(got - ref)[ok] / np.maximum(np.abs(ref[ok]), 1.0)) if ok.any() else 0.0
+        rel = np.where(ok, np.abs(got - ref) / np.maximum(np.abs(ref), 1.0), 0.0)
+        lag_err = float(rel.max()) if ok.any() else 0.0
         peak_err = np.max(np.abs(pk[ok] - rp[ok]) / np.maximum(np.abs(rp[ok]), 1e-30)) if ok.any() else 0.0
         unexcused = int(np.sum(bad & ~excused))
-        tol_fail = int(lag_err > TOL) + int(peak_err > TOL)
+        # a lag beyond 1e-5 is a failure unless the parabola itself is that ill-conditioned: one float32 ulp on the
+        # oracle's own taps moves the result by `bound`; four of those are allowed (two roundings per transform)
+        ill = 0
+        lag_fail = 0
+        if lag_err > TOL:
+            plist = orc.pair_list(B) if pairs is None else pairs
+            for w, q in zip(*np.nonzero(rel > TOL)):
+                bound = parabola_ulp_bound(orc, iq[w, int(plist[q, 0])], iq[w, int(plist[q, 1])])
+                if rel[w, q] <= 4.0 * bound:
+                    ill += 1
+                else:
+                    lag_fail += 1
+        n_ill += ill
+        tol_fail = lag_fail + int(peak_err > TOL)
         n_cases += 1
         n_pw += li.size
         n_excused += int(excused.sum())
@@ -159,8 +195,8 @@ def main():
         print(f"case {case:4d}  N={N:7d} B={B:2d} W={W:5d} {'u8 ' if u8 else 'c64'} snr={snr:4.1f} "
               f"pairs={'all' if pairs is None else len(pairs):>4} seed={seed:10d}  pair-windows={li.size:7d} "
               f"int-mismatch={int(bad.sum())} (excused {int(excused.sum())})  lag_err={lag_err:.2e} peak_err={peak_err:.2e} "
-              f"gpu={t_gpu * 1e3:7.1f} ms{'  FAIL' if unexcused or tol_fail else ''}", flush=True)
-    print(f"SUMMARY: {n_cases} cases, {n_pw} pair-windows, {n_bad} failures, {n_excused} excused near-ties, "
+              f"gpu={t_gpu * 1e3:7.1f} ms{'  (%d flat-peak lags within 4 ulp of the taps)' % ill if ill else ''}{'  FAIL' if unexcused or tol_fail else ''}", flush=True)
+    print(f"SUMMARY: {n_cases} cases, {n_pw} pair-windows, {n_bad} failures, {n_excused} excused near-ties, {n_ill} flat-peak lags beyond 1e-5 but within 4 ulp of the oracle's taps, "
           f"worst relative lag error {worst_lag:.2e}, worst relative peak error {worst_peak:.2e}")
     print("pair-windows per window length: " + ", ".join(f"{n}: {c}" for n, c in sorted(by_n.items())))
     return 1 if n_bad else 0
