@@ -741,3 +741,25 @@ def test_seeded_random_shapes_and_pair_lists(xc, case):
     with xc.XcorrEngine(B, N, W) as eng:
         li, lf, pk = eng.correlate(iq, pairs) if pairs is not None else eng.correlate(iq)
     _assert_parity(li, lf, pk, ri, rf, rp, margin, second)
+
+
+def test_fused_kernel_half_order_modes_and_grid_sizes(xc, opts):
+    """k_win's kernel-selection options change scheduling only: every half-order mode (`stag` 0..5) and persistent grids
+    smaller than, equal to and larger than the window count (`ncus`: workgroups that take 3 windows, 1 window, none) must
+    give the results of the default build bit for bit, on 3 and 8 buoys, complex64 and raw uint8."""
+    for B, W in ((8, 37), (3, 300)):
+        out = rm.synth.make_windows(W, B, 4096, 10e6, seed=4242 + B, return_u8=True)
+        iq, raw = out[0], out[2]
+        ri, rf, rp = orc.xcorr_batch_fast(iq, workers=8)
+        with xc.XcorrEngine(B, 4096, W) as eng:
+            base = eng.correlate(iq)
+            _assert_parity(*base, ri, rf, rp)
+        for key, values in (("stag", (0, 2, 3, 4, 5)), ("ncus", (1, 16, W, 2 * W + 3))):
+            for v in values:
+                opts(key, v)
+                with xc.XcorrEngine(B, 4096, W) as eng:
+                    got = eng.correlate(iq)
+                    got8 = eng.correlate(raw)
+                xc.clear_default_options()
+                for a, b, c in zip(base, got, got8):
+                    assert np.array_equal(a, b) and np.array_equal(a, c), (key, v, B)
