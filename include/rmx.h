@@ -91,7 +91,11 @@ int rmx_set_stream(rmx_ctx* ctx, void* hip_stream);
 /* Per-ctx options (all optional): "chunk_windows" (windows per launch), "timing" (1: bracket every
  * launch with HIP events, read back with rmx_last_timing), "fused" (default 1; 0 forces the separate
  * forward + pair kernels that custom pair lists use), "resident" and "pairs_per_block" (variants of
- * that unfused pair kernel), "stag" (0..5: which waves of the fused N = 4096 kernel run the two halves
+ * that unfused pair kernel; without an explicit "pairs_per_block" the library sizes the blocks to the batch),
+ * "small4096" (default 1: batches of N = 4096 too small to fill the chip with one workgroup per window -- fewer than
+ * about 0.25 ... 0.5 windows per CU, depending on the buoy count -- run through those per-transform kernels, which spread
+ * one window's spectra and pairs over the CUs: 13 us instead of 92 us for a single window of 8 buoys; 0: always the
+ * fused kernel), "stag" (0..5: which waves of the fused N = 4096 kernel run the two halves
  * between barriers in the opposite order; default 1), "win8" / "pk" (the two other builds of that kernel,
  * present only in a -DRMX_EXPERIMENTS build, RMX_E_UNSUPPORTED otherwise), "dbg"
  * (ablation masks of the -DRMX_ABLATE timing build; every other build rejects the key with
@@ -102,7 +106,7 @@ int rmx_set_option(rmx_ctx* ctx, const char* key, long value);
 /* Kernel-selection defaults for engines created AFTERWARDS (process-wide; an existing ctx keeps the values it was
  * created with, so its kernels, block sizes and LDS sizes stay consistent).  For tests and A/B measurements: the
  * library never reads the environment.  Keys (radio-mapper_amd/csrc/host_plan.hpp lists ranges and meanings):
- * "stag", "ncus", "chunk_windows", "generic4096", "small_maxl", "logl1", "wfused", "wscr", "wscr14",
+ * "stag", "ncus", "chunk_windows", "small4096", "generic4096", "small_maxl", "logl1", "wfused", "wscr", "wscr14",
  * "wscr_per_cu", "rows_anchor", "fused", "fused_def", "gen_chunk", "rows_tpr", "cols_threads", "col_logt".
  * Returns RMX_E_INVAL (text through rmx_last_error(NULL)) for an unknown key or a value out of range;
  * value == LONG_MIN removes a key; rmx_clear_default_options() removes all. */

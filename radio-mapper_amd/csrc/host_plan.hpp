@@ -35,6 +35,7 @@ inline const std::vector<OptionSpec>& option_specs() {
         {"stag", 0, 5, "N = 4096 fused kernel: which waves run the two halves between barriers in the opposite order (default 1)"},
         {"ncus", 1, 4096, "persistent workgroups of the fused N = 4096 kernel (default: one per CU)"},
         {"chunk_windows", 1, 1 << 20, "windows per chunk of the unfused N = 4096 path"},
+        {"small4096", 0, 1, "0: N = 4096 through the fused kernel however few the windows (default 1: few windows through the per-transform kernels)"},
         {"generic4096", 0, 1, "1: N = 4096 through the generic whole-window kernels instead of k_win"},
         {"small_maxl", 256, 16384, "largest zero-padded length that runs as one LDS transform per workgroup (default 8192)"},
         {"logl1", 4, 10, "four-step: log2 of the column length"},

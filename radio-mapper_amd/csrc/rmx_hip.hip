@@ -611,6 +611,8 @@ struct rmx_ctx {
     bool own_stream = false;
     int chunk_windows = 0;
     int pairs_per_block = 7;
+    bool ppb_user = false;  // set through rmx_set_option: the small-batch rule then leaves it alone
+    bool small_batch = true; // option small4096: few windows of N = 4096 through the per-transform kernels (see rmx_xcorr_batch)
     bool timing = false;
     int dbg = 0;
     bool resident = true;
@@ -1424,6 +1426,7 @@ int rmx_create(rmx_ctx** out, int device_id, int n_buoys, int n_samples, int max
         RMX_HIP(c, hipMemcpy(c->d_tw2, tw2.data(), tw2.size() * sizeof(float2), hipMemcpyHostToDevice));
         c->scratch_bytes = c->spec_bytes + tw1.size() * sizeof(float4) + tw2.size() * sizeof(float2);
         c->stag = (int)c->knobs.get_or("stag", 1);
+        c->small_batch = c->knobs.get_or("small4096", 1) != 0;
 #ifdef RMX_EXPERIMENTS
         {   // the two other builds of the fused kernel: measured slower, not in the default build
             std::vector<float4> t1;
@@ -1528,6 +1531,7 @@ int rmx_set_option(rmx_ctx* c, const char* key, long value) {
     if (!strcmp(key, "pairs_per_block")) {
         if (value < 1 || value > 1 << 20) return fail(c, RMX_E_INVAL, "pairs_per_block %ld out of range", value);
         c->pairs_per_block = (int)value;
+        c->ppb_user = true;
         return RMX_OK;
     }
     if (!strcmp(key, "dbg")) {
@@ -1549,6 +1553,10 @@ int rmx_set_option(rmx_ctx* c, const char* key, long value) {
     if (!strcmp(key, "stag")) {
         if (value < 0 || value > 5) return fail(c, RMX_E_INVAL, "stag %ld not in 0..5", value);
         c->stag = (int)value;
+        return RMX_OK;
+    }
+    if (!strcmp(key, "small4096")) {
+        c->small_batch = value != 0;
         return RMX_OK;
     }
     if (!strcmp(key, "fused")) {
@@ -1657,8 +1665,29 @@ int rmx_xcorr_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pa
     if (n_pairs < 0) return fail(c, RMX_E_INVAL, "n_pairs %d < 0", n_pairs);
     if (n_windows == 0 || n_pairs == 0) return RMX_OK;
     RMX_HIP(c, hipSetDevice(c->device));
+    // Few windows of N = 4096: the fused kernel is one workgroup per WINDOW -- (B + P) transforms in sequence, 92 us for
+    // one window of 8 buoys, 344 us for 16 buoys, whatever the rest of the chip does -- while the per-transform kernels
+    // spread a window's spectra and pairs over the CUs: 13-15 us for the same single windows (tools/exp_small4096.py;
+    // the crossover sits at 64 / 110 / 140 windows for 3 / 8 / 16 buoys).  This is the shape of the reference's seam:
+    // one frequency group per call (tdoa_processor.py:363-377).  Pairs per workgroup then follow the batch so that the
+    // pair kernel's grid is about one workgroup per CU.
+    bool small = false;
+    if (!c->generic && c->fused && c->small_batch && c->n_buoys >= 3 && n_pairs == all_pairs) {
+        double k = 0.2 + 0.02 * c->n_buoys;
+        if (k > 0.5) k = 0.5;
+        small = n_windows < (long)(k * c->n_cus);
+    }
+    if (!c->generic && !c->ppb_user) {
+        int ppb = 7;
+        if (small) {
+            const long want = ((long)n_windows * n_pairs + c->n_cus - 1) / c->n_cus;
+            ppb = want < 1 ? 1 : (want > 7 ? 7 : (int)want);
+        }
+        c->pairs_per_block = ppb;
+    }
     int rc = build_plan(c, pairs, n_pairs);
     if (rc != RMX_OK) return rc;
+    const bool fused_now = c->fused && c->plan_all_pairs && !small;
 
     const bool in_dev = flags & RMX_IN_DEVICE, out_dev = flags & RMX_OUT_DEVICE, u8 = flags & RMX_IN_U8;
     const size_t samp_bytes = u8 ? 2 : 8;
@@ -1675,7 +1704,7 @@ int rmx_xcorr_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pa
         }
         // fused path: the copy is cut into sub-chunks issued on a second stream, each followed by its
         // kernel launch, so that copy k+1 travels while kernel k runs (below); otherwise one copy up front
-        pipelined = !c->generic && c->fused && c->plan_all_pairs && n_windows > kHostSubChunk;
+        pipelined = !c->generic && fused_now && n_windows > kHostSubChunk;
         if (pipelined) {
             if (!c->copy_stream) RMX_HIP(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
             for (hipEvent_t& e : c->copy_ev)
@@ -1720,7 +1749,7 @@ int rmx_xcorr_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pa
     const float out_scale = out_scale4096();   // (the forward scale 2^-6 rides on the TW1 table)
 
     {   // scratch: per workgroup for the fused kernel, per window of a chunk otherwise
-        const bool fused_path = c->fused && c->plan_all_pairs;
+        const bool fused_path = fused_now;
         const long chunk_w = n_windows < c->chunk_windows ? n_windows : c->chunk_windows;
         rc = ensure_spec(c, fused_path ? (chunk_w < c->n_cus ? chunk_w : c->n_cus) : chunk_w);
         if (rc != RMX_OK) return rc;
@@ -1736,7 +1765,7 @@ int rmx_xcorr_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pa
     int n_sub = 0;
     for (int w0 = 0; w0 < n_windows; w0 += c->chunk_windows) {
         const int wc = (n_windows - w0 < c->chunk_windows) ? n_windows - w0 : c->chunk_windows;
-        if (c->fused && c->plan_all_pairs) {
+        if (fused_now) {
             const int sub = pipelined ? kHostSubChunk : wc;
             for (int s0 = 0; s0 < wc; s0 += sub) {
                 const int sc = wc - s0 < sub ? wc - s0 : sub;

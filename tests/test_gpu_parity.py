@@ -744,18 +744,20 @@ def test_seeded_random_shapes_and_pair_lists(xc, case):
 
 
 def test_fused_kernel_half_order_modes_and_grid_sizes(xc, opts):
-    """k_win's kernel-selection options change scheduling only: every half-order mode (`stag` 0..5) and persistent grids
+    """k_win's scheduling options change scheduling only: every half-order mode (`stag` 0..5) and persistent grids
     smaller than, equal to and larger than the window count (`ncus`: workgroups that take 3 windows, 1 window, none) must
     give the results of the default build bit for bit, on 3 and 8 buoys, complex64 and raw uint8."""
     for B, W in ((8, 37), (3, 300)):
         out = rm.synth.make_windows(W, B, 4096, 10e6, seed=4242 + B, return_u8=True)
         iq, raw = out[0], out[2]
         ri, rf, rp = orc.xcorr_batch_fast(iq, workers=8)
+        opts("small4096", 0)      # the fused kernel also for these few windows (by default they take the per-transform kernels)
         with xc.XcorrEngine(B, 4096, W) as eng:
             base = eng.correlate(iq)
             _assert_parity(*base, ri, rf, rp)
         for key, values in (("stag", (0, 2, 3, 4, 5)), ("ncus", (1, 16, W, 2 * W + 3))):
             for v in values:
+                opts("small4096", 0)
                 opts(key, v)
                 with xc.XcorrEngine(B, 4096, W) as eng:
                     got = eng.correlate(iq)
@@ -763,3 +765,27 @@ def test_fused_kernel_half_order_modes_and_grid_sizes(xc, opts):
                 xc.clear_default_options()
                 for a, b, c in zip(base, got, got8):
                     assert np.array_equal(a, b) and np.array_equal(a, c), (key, v, B)
+
+
+@pytest.mark.parametrize("B,W", [(3, 1), (8, 1), (8, 5), (16, 2), (8, 60), (5, 40)])
+def test_small_batches_take_the_per_transform_kernels(xc, opts, B, W):
+    """Few windows of N = 4096 (the reference's seam hands over one frequency group at a time) run through k_fwd + the pair
+    kernels with the blocks sized to the batch instead of one workgroup per window: same bar against the oracle, complex64
+    and uint8 identical, and the same integer lags as the fused kernel (option small4096 = 0) on the same input."""
+    out = rm.synth.make_windows(W, B, 4096, 10e6, seed=900 + 17 * B + W, return_u8=True)
+    iq, raw = out[0], out[2]
+    ri, rf, rp = orc.xcorr_batch_fast(iq, workers=8)
+    with xc.XcorrEngine(B, 4096, max(W, 8)) as eng:
+        got = eng.correlate(iq)
+        _assert_parity(*got, ri, rf, rp)
+        got8 = eng.correlate(raw)
+        for a, b in zip(got, got8):
+            assert np.array_equal(a, b)
+        again = eng.correlate(iq)                       # plan and scratch reused
+        for a, b in zip(got, again):
+            assert np.array_equal(a, b)
+    opts("small4096", 0)
+    with xc.XcorrEngine(B, 4096, max(W, 8)) as eng:
+        fused = eng.correlate(iq)
+    assert np.array_equal(got[0], fused[0])
+    assert np.allclose(got[1], fused[1], atol=2e-5) and np.allclose(got[2], fused[2], rtol=1e-5)
