@@ -789,3 +789,22 @@ def test_small_batches_take_the_per_transform_kernels(xc, opts, B, W):
         fused = eng.correlate(iq)
     assert np.array_equal(got[0], fused[0])
     assert np.allclose(got[1], fused[1], atol=2e-5) and np.allclose(got[2], fused[2], rtol=1e-5)
+
+
+def test_one_engine_alternates_between_small_and_large_batches(xc):
+    """One ctx, calls of 1, 300, 2, 300 and 1 windows: the dispatch (per-transform kernels below the rule's limit, the fused
+    kernel above), the pair plan's block size and the scratch size change from call to call; every call meets the bar and
+    repeated batches give identical arrays."""
+    B = 8
+    out = rm.synth.make_windows(300, B, 4096, 10e6, seed=31337, return_u8=True)
+    iq = out[0]
+    ri, rf, rp = orc.xcorr_batch_fast(iq, workers=8)
+    seen = {}
+    with xc.XcorrEngine(B, 4096, 300) as eng:
+        for W in (1, 300, 2, 300, 1):
+            got = eng.correlate(iq[:W])
+            _assert_parity(*got, ri[:W], rf[:W], rp[:W])
+            if W in seen:
+                for a, b in zip(seen[W], got):
+                    assert np.array_equal(a, b)
+            seen[W] = got
