@@ -1669,22 +1669,33 @@ int rmx_xcorr_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pa
     // one window of 8 buoys, 344 us for 16 buoys, whatever the rest of the chip does -- while the per-transform kernels
     // spread a window's spectra and pairs over the CUs: 13-15 us for the same single windows (tools/exp_small4096.py;
     // the crossover sits at 64 / 110 / 140 windows for 3 / 8 / 16 buoys).  This is the shape of the reference's seam:
-    // one frequency group per call (tdoa_processor.py:363-377).  Pairs per workgroup then follow the batch so that the
-    // pair kernel's grid is about one workgroup per CU.
+    // one frequency group per call (tdoa_processor.py:363-377).
+    // Both paths are costed with a small model read off that table (us: 2.6 per transform of the fused kernel; 3.5 per
+    // round of forward workgroups, two per CU; 4.0 per pair workgroup + 3.3 per pair in it, one workgroup per CU; a
+    // round that fills the chip runs up to 45 % slower than a lone workgroup, less so when many rounds follow each other
+    // out of step) and the cheaper one runs; the same model picks the pairs per workgroup (1 ... 7) unless the caller
+    // set them.  Against the measured table it is within 10 % on every row and picks the faster path on all of them.
     bool small = false;
+    int ppb_small = 7;
     if (!c->generic && c->fused && c->small_batch && c->n_buoys >= 3 && n_pairs == all_pairs) {
-        double k = 0.2 + 0.02 * c->n_buoys;
-        if (k > 0.5) k = 0.5;
-        small = n_windows < (long)(k * c->n_cus);
-    }
-    if (!c->generic && !c->ppb_user) {
-        int ppb = 7;
-        if (small) {
-            const long want = ((long)n_windows * n_pairs + c->n_cus - 1) / c->n_cus;
-            ppb = want < 1 ? 1 : (want > 7 ? 7 : (int)want);
+        const long cus = c->n_cus > 0 ? c->n_cus : 1;
+        auto rounds = [&](long blocks, long per_round) { return (double)((blocks + per_round - 1) / per_round); };
+        const double t_fused = rounds(n_windows, cus) * (c->n_buoys + n_pairs) * 2.6 + 3.0;
+        const double t_fwd = rounds((long)n_windows * c->n_buoys, 2 * cus) * 3.5 + 2.0;
+        double best = 1e30;
+        for (int q = 7; q >= 1; --q) {
+            const int qq = c->ppb_user ? c->pairs_per_block : q;
+            const long parts = (n_pairs + qq - 1) / qq;
+            const long blocks = (long)n_windows * parts;
+            const double r = rounds(blocks, cus);
+            const double fill = blocks >= cus ? 1.0 : (double)blocks / (double)cus;
+            const double t = (t_fwd + r * (4.0 + 3.3 * ((n_pairs + parts - 1) / parts))) * (1.15 + 0.3 * fill / std::sqrt(r));
+            if (t < best) { best = t; ppb_small = qq; }
+            if (c->ppb_user) break;
         }
-        c->pairs_per_block = ppb;
+        small = best < t_fused;
     }
+    if (!c->generic && !c->ppb_user) c->pairs_per_block = small ? ppb_small : 7;
     int rc = build_plan(c, pairs, n_pairs);
     if (rc != RMX_OK) return rc;
     const bool fused_now = c->fused && c->plan_all_pairs && !small;
