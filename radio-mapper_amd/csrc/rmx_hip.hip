@@ -1650,6 +1650,26 @@ static float out_scale4096() {
     return std::ldexp(1.0f, 3 * kTw1ScaleLog2 - logl);
 }
 
+// N = 4096, per-transform kernels: estimated us of k_fwd + the pair kernel for n_windows x n_pairs, and the pairs per
+// workgroup (1 ... 7, or the caller's) that minimise it -- the model of rmx_xcorr_batch's small-batch rule
+static double split_cost4096(const rmx_ctx* c, int n_windows, int n_pairs, int* ppb) {
+    const long cus = c->n_cus > 0 ? c->n_cus : 1;
+    auto rounds = [&](long blocks, long per_round) { return (double)((blocks + per_round - 1) / per_round); };
+    const double t_fwd = rounds((long)n_windows * c->n_buoys, 2 * cus) * 3.5 + 2.0;
+    double best = 1e30;
+    for (int q = 7; q >= 1; --q) {
+        const int qq = c->ppb_user ? c->pairs_per_block : q;
+        const long parts = (n_pairs + qq - 1) / qq;
+        const long blocks = (long)n_windows * parts;
+        const double r = rounds(blocks, cus);
+        const double fill = blocks >= cus ? 1.0 : (double)blocks / (double)cus;
+        const double t = (t_fwd + r * (4.0 + 3.3 * ((n_pairs + parts - 1) / parts))) * (1.15 + 0.3 * fill / std::sqrt(r));
+        if (t < best) { best = t; *ppb = qq; }
+        if (c->ppb_user) break;
+    }
+    return best;
+}
+
 int rmx_xcorr_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pairs, int n_pairs,
                     int32_t* lag_int, float* lag_frac, float* peak, unsigned flags) {
     if (!c) return RMX_E_INVAL;
@@ -1679,21 +1699,8 @@ int rmx_xcorr_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pa
     int ppb_small = 7;
     if (!c->generic && c->fused && c->small_batch && c->n_buoys >= 3 && n_pairs == all_pairs) {
         const long cus = c->n_cus > 0 ? c->n_cus : 1;
-        auto rounds = [&](long blocks, long per_round) { return (double)((blocks + per_round - 1) / per_round); };
-        const double t_fused = rounds(n_windows, cus) * (c->n_buoys + n_pairs) * 2.6 + 3.0;
-        const double t_fwd = rounds((long)n_windows * c->n_buoys, 2 * cus) * 3.5 + 2.0;
-        double best = 1e30;
-        for (int q = 7; q >= 1; --q) {
-            const int qq = c->ppb_user ? c->pairs_per_block : q;
-            const long parts = (n_pairs + qq - 1) / qq;
-            const long blocks = (long)n_windows * parts;
-            const double r = rounds(blocks, cus);
-            const double fill = blocks >= cus ? 1.0 : (double)blocks / (double)cus;
-            const double t = (t_fwd + r * (4.0 + 3.3 * ((n_pairs + parts - 1) / parts))) * (1.15 + 0.3 * fill / std::sqrt(r));
-            if (t < best) { best = t; ppb_small = qq; }
-            if (c->ppb_user) break;
-        }
-        small = best < t_fused;
+        const double t_fused = (double)((n_windows + cus - 1) / cus) * (c->n_buoys + n_pairs) * 2.6 + 3.0;
+        small = split_cost4096(c, n_windows, n_pairs, &ppb_small) < t_fused;
     }
     if (!c->generic && !c->ppb_user) c->pairs_per_block = small ? ppb_small : 7;
     int rc = build_plan(c, pairs, n_pairs);
@@ -1862,6 +1869,11 @@ int rmx_caf_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pair
     if (n_pairs < 0) return fail(c, RMX_E_INVAL, "n_pairs %d < 0", n_pairs);
     if (n_windows == 0 || n_pairs == 0) return RMX_OK;
     RMX_HIP(c, hipSetDevice(c->device));
+    if (!c->generic && !c->ppb_user) {               // (N = 4096: blocks sized to this batch, not to the previous call's)
+        int q = 7;
+        (void)split_cost4096(c, n_windows, n_pairs, &q);
+        c->pairs_per_block = q;
+    }
     int rc = build_plan(c, pairs, n_pairs);          // validates the pair list
     if (rc != RMX_OK) return rc;
     const bool in_dev = flags & RMX_IN_DEVICE, out_dev = flags & RMX_OUT_DEVICE, u8 = flags & RMX_IN_U8;
