@@ -1702,12 +1702,26 @@ int rmx_xcorr_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pa
         const double t_fused = (double)((n_windows + cus - 1) / cus) * (c->n_buoys + n_pairs) * 2.6 + 3.0;
         small = split_cost4096(c, n_windows, n_pairs, &ppb_small) < t_fused;
     }
-    if (!c->generic && !c->ppb_user) c->pairs_per_block = small ? ppb_small : 7;
+    const bool in_dev = flags & RMX_IN_DEVICE, out_dev = flags & RMX_OUT_DEVICE, u8 = flags & RMX_IN_U8;
+    // The same arithmetic for the LAST round of a larger batch: W = k CUs + r windows cost the fused kernel k + 1 rounds
+    // (300 windows of 8 buoys: two rounds, 184 us); when the model says the r windows are cheaper through the
+    // per-transform kernels than a round of the fused one, they go there (after the k full rounds, on the same stream).
+    int tail = 0;
+    if (!small && !c->generic && c->fused && c->small_batch && c->n_buoys >= 3 && n_pairs == all_pairs && c->n_cus > 0 &&
+        n_windows > c->n_cus && n_windows % c->n_cus != 0 && (in_dev || n_windows <= kHostSubChunk)) {
+        int q = 7;
+        const int r = n_windows % c->n_cus;
+        if (split_cost4096(c, r, n_pairs, &q) < 0.9 * ((c->n_buoys + n_pairs) * 2.6 + 3.0)) {
+            tail = r;
+            ppb_small = q;
+        }
+    }
+    if (!c->generic && !c->ppb_user) c->pairs_per_block = (small || tail) ? ppb_small : 7;
     int rc = build_plan(c, pairs, n_pairs);
     if (rc != RMX_OK) return rc;
     const bool fused_now = c->fused && c->plan_all_pairs && !small;
+    if (!fused_now) tail = 0;
 
-    const bool in_dev = flags & RMX_IN_DEVICE, out_dev = flags & RMX_OUT_DEVICE, u8 = flags & RMX_IN_U8;
     const size_t samp_bytes = u8 ? 2 : 8;
     const size_t in_bytes = (size_t)n_windows * c->n_buoys * c->n_samples * samp_bytes;
     const void* d_iq = iq;
@@ -1777,16 +1791,18 @@ int rmx_xcorr_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pa
     c->ev_kind.clear();
     if (c->timing) {
         const size_t subs = pipelined ? (size_t)(n_windows + kHostSubChunk - 1) / kHostSubChunk + n_chunks : n_chunks;
-        rc = ensure_events(c, subs * 4);
+        rc = ensure_events(c, subs * 4 + 8);
         if (rc != RMX_OK) return rc;
     }
     int n_sub = 0;
     for (int w0 = 0; w0 < n_windows; w0 += c->chunk_windows) {
         const int wc = (n_windows - w0 < c->chunk_windows) ? n_windows - w0 : c->chunk_windows;
         if (fused_now) {
-            const int sub = pipelined ? kHostSubChunk : wc;
-            for (int s0 = 0; s0 < wc; s0 += sub) {
-                const int sc = wc - s0 < sub ? wc - s0 : sub;
+            const int wtail = (tail && w0 + wc == n_windows) ? tail : 0;   // the batch's last partial round (see above)
+            const int wf = wc - wtail;
+            const int sub = pipelined ? kHostSubChunk : (wf > 0 ? wf : 1);
+            for (int s0 = 0; s0 < wf; s0 += sub) {
+                const int sc = wf - s0 < sub ? wf - s0 : sub;
                 const long wfirst = (long)w0 + s0;
                 if (pipelined) {
                     const size_t off = (size_t)wfirst * c->n_buoys * c->n_samples * samp_bytes;
@@ -1834,6 +1850,12 @@ int rmx_xcorr_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pa
                     c->ev_used += 2;
                     c->ev_kind.push_back(1);
                 }
+            }
+            if (wtail) {
+                rc = fwd4096(c, d_iq, w0 + wf, wtail, u8, nullptr);
+                if (rc != RMX_OK) return rc;
+                rc = pairs4096(c, w0 + wf, wtail, n_pairs, d_lag, d_frac, d_peak, out_scale, false);
+                if (rc != RMX_OK) return rc;
             }
             continue;
         }

@@ -808,3 +808,28 @@ def test_one_engine_alternates_between_small_and_large_batches(xc):
                 for a, b in zip(seen[W], got):
                     assert np.array_equal(a, b)
             seen[W] = got
+
+
+def test_partial_last_round_goes_through_the_per_transform_kernels(xc, opts):
+    """W = k CUs + r windows: the k full rounds run in the fused kernel, the r windows of the last, partial round in the
+    per-transform kernels when the cost model prefers that (the chunk boundary at 4096 windows included); bar against the
+    oracle on every window, integer lags equal to the all-fused run (option small4096 = 0)."""
+    from radio_mapper_amd import xcorr as x
+    n_cus = 256
+    for B, W in ((8, n_cus + 44), (3, 2 * n_cus + 5), (8, 4096 + 100)):
+        out = rm.synth.make_windows(min(W, 512), B, 4096, 10e6, seed=77 + W, return_u8=True)
+        iq = np.concatenate([out[0]] * ((W + 511) // 512))[:W]
+        ri, rf, rp = orc.xcorr_batch_fast(iq[:512], workers=8)
+        reps = (W + 511) // 512
+        ri, rf, rp = (np.concatenate([a] * reps)[:W] for a in (ri, rf, rp))
+        with xc.XcorrEngine(B, 4096, W) as eng:
+            got = eng.correlate(iq)
+        _assert_parity(*got, ri, rf, rp)
+        opts("small4096", 0)
+        with xc.XcorrEngine(B, 4096, W) as eng:
+            fused = eng.correlate(iq)
+        x.clear_default_options()
+        assert np.array_equal(got[0], fused[0])
+        k = (W // n_cus) * n_cus                      # the full rounds are the same kernel on the same data
+        for a, b in zip(got, fused):
+            assert np.array_equal(a[:k], b[:k])

@@ -32,7 +32,7 @@ def run(B, W, opts):
 
 
 for B in (3, 8, 16):
-    for W in (1, 4, 16, 32, 64, 128, 256):
+    for W in (1, 4, 16, 32, 64, 128, 256, 300, 600, 1100):
         auto, ref = run(B, W, {})
         base, ref0 = run(B, W, {"small4096": 0})
         row = [f"default {auto:7.1f}{'' if np.array_equal(ref, ref0) else ' !!'}", f"fused {base:7.1f}"]
