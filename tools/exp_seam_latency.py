@@ -2,7 +2,6 @@
 usage: python tools/exp_seam_latency.py"""
 import sys, time
 sys.path.insert(0, '.')
-import numpy as np
 import radio_mapper_amd as rm
 from radio_mapper_amd import xcorr, tdoa_processor as tp
 
