@@ -158,6 +158,12 @@ class TDoACalculator:
         if eng is None or eng.max_windows < n_windows:
             if eng is not None:
                 eng.close()
+            # head room: the number of frequency groups varies from call to call at the seam, and an engine is only
+            # rebuilt (milliseconds: tables, scratch) when a batch exceeds every earlier one by a power of two
+            cap = 8
+            while cap < n_windows:
+                cap *= 2
+            n_windows = cap
             devs = self.devices
             if isinstance(devs, str):
                 if devs != "all":

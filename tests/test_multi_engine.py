@@ -94,7 +94,7 @@ def test_calculator_uses_the_multi_engine_for_several_devices(monkeypatch):
     tp.TDoACalculator(devices="all").measure_lags(iq)
     tp.TDoACalculator(devices=[2]).measure_lags(iq)
     tp.TDoACalculator(device=1).measure_lags(iq)
-    assert made == [(3, 8, 6, [0, 1]), (3, 8, 6, [0, 1, 2, 3]), (3, 8, 6, 2), (3, 8, 6, 1)]
+    assert made == [(3, 8, 8, [0, 1]), (3, 8, 8, [0, 1, 2, 3]), (3, 8, 8, 2), (3, 8, 8, 1)]   # (6 windows: capacity 8)
 
 
 @pytest.mark.gpu
