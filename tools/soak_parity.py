@@ -45,6 +45,65 @@ def parabola_ulp_bound(orc, x_i, x_j):
     return (abs(pa) + abs(pb) + abs(pc)) * ulp / max(abs(lag), 1.0)
 
 
+def soak_detect(args, rng, t_end, xcorr):
+    """rmx_detect_batch against oracle.detect_ref (the reference's own scipy calls) with the rule of tests/test_detect.py:
+    identical peak sets, or a near-tie (< 1e-3 dB) somewhere in the window that explains the difference; noise floor,
+    power and snr within 4e-4 dB on identical sets."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    from oracle import detect_ref as dr
+    from test_detect import make_windows, _margin
+    n_win = n_exact = n_tie = n_bad = n_dyn = 0
+    worst = 0.0
+    case = 0
+    with xcorr.XcorrEngine(2, 4096, 1) as eng:
+        while time.time() < t_end:
+            case += 1
+            N = 1 << int(rng.choice([6, 8, 9, 10, 11, 12, 13, 14]))
+            W = int(rng.choice([1, 2, 5, 16, 40]))
+            u8 = bool(rng.integers(0, 2))
+            tones = int(rng.integers(0, 7))
+            dist = int(rng.choice([10, 10, 3, 25]))
+            seed = int(rng.integers(1, 2 ** 31 - 1))
+            x, raw = make_windows(W, N, seed=seed, tones=tones, u8=u8)
+            dc = 10e3 * N / 2.4e6
+            ref = dr.detect_batch(x, dc_exclude_bins=dc, distance=dist)
+            got = eng.detect(raw if u8 else x, dc_exclude_bins=dc, distance=dist, max_peaks=max(N // 4, 16))
+            exact = tie = bad = 0
+            for w in range(W):
+                rb, rp, rs, rc, rf = ref[w]
+                gb, gp, gs, gc, gf = got[w]
+                ok_floor = abs(gf - rf) < 2e-4
+                if np.array_equal(gb, rb):
+                    d = max(float(np.abs(gp - rp).max()) if len(rb) else 0.0, float(np.abs(gs - rs).max()) if len(rb) else 0.0)
+                    worst = max(worst, d)
+                    if ok_floor and d < 4e-4:
+                        exact += 1
+                    elif ok_floor and len(rb):
+                        # a weak peak next to tones 50 dB stronger: the ORACLE's float32 spectrum is itself that far from a
+                        # float64 one there (its transform's error rides on the strongest bin); allow four times that
+                        p32 = dr.power_spectrum_db(x[w]).astype(np.float64)
+                        p64 = 20.0 * np.log10(np.abs(np.fft.fft(x[w].astype(np.complex128))) + 1e-12)
+                        own = float(np.abs(p32[rb] - p64[rb]).max())
+                        if d <= 4.0 * own + 1e-5:
+                            exact += 1
+                            n_dyn += 1
+                        else:
+                            bad += 1
+                    else:
+                        bad += 1
+                elif ok_floor and _margin(dr.power_spectrum_db(x[w]), rf, dist, 0.3) < 1e-3:
+                    tie += 1
+                else:
+                    bad += 1
+            n_win += W; n_exact += exact; n_tie += tie; n_bad += bad
+            print(f"detect case {case:4d}  N={N:6d} W={W:3d} {'u8 ' if u8 else 'c64'} tones={tones} distance={dist:2d} seed={seed:10d}  "
+                  f"identical={exact} near-tie={tie} bad={bad}{'  FAIL' if bad else ''}", flush=True)
+    print(f"SUMMARY (detect): {case} cases, {n_win} windows, {n_exact} identical peak sets, {n_tie} explained by a near-tie (< 1e-3 dB), "
+          f"{n_bad} failures, worst dB difference on identical sets {worst:.2e} ({n_dyn} windows beyond 4e-4 dB but within four times the "
+          f"oracle's own float32 error against a float64 spectrum at those bins)")
+    return 1 if n_bad else 0
+
+
 def soak_caf(args, rng, t_end, rm, xcorr, orc):
     """rmx_caf_batch against oracle.caf_batch (a Python loop over windows x pairs x hypotheses: small cases only).  A
     (Doppler index, lag) that differs from the oracle's is excused only when the oracle's own peak at the GPU's
@@ -108,6 +167,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--max-bytes", type=float, default=3.0e8, help="largest input batch in bytes (complex64)")
     ap.add_argument("--caf", action="store_true", help="soak rmx_caf_batch (Doppler grid) instead of rmx_xcorr_batch")
+    ap.add_argument("--detect", action="store_true", help="soak rmx_detect_batch (spectral detection) against oracle/detect_ref.py")
     args = ap.parse_args()
 
     import __graft_entry__ as g
@@ -121,6 +181,8 @@ def main():
     t_end = time.time() + args.seconds
     if args.caf:
         return soak_caf(args, rng, t_end, rm, xcorr, orc)
+    if args.detect:
+        return soak_detect(args, rng, t_end, xcorr)
     n_cases = n_pw = n_excused = n_bad = n_ill = 0
     worst_lag = worst_peak = 0.0
     by_n = {}
