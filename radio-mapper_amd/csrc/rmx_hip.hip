@@ -630,7 +630,8 @@ struct rmx_ctx {
     rmx::PairItem* d_items = nullptr;
     int* d_part_begin = nullptr;
     void* d_in = nullptr;      size_t d_in_bytes = 0;
-    int* d_lag = nullptr;      float* d_frac = nullptr;  float* d_peak = nullptr;  size_t d_out_elems = 0;
+    int* d_lag = nullptr;      float* d_frac = nullptr;  float* d_peak = nullptr;  size_t d_out_elems = 0;   // ONE block: lag | frac | peak
+    void* h_out = nullptr;     size_t h_out_bytes = 0;   // pinned staging of small host-pointer results (fetch_out)
     size_t spec_bytes = 0, scratch_bytes = 0;
     // generic path (n_samples != 4096): see generic_path.hpp
     bool generic = false;
@@ -1488,9 +1489,8 @@ void rmx_destroy(rmx_ctx* c) {
     if (c->d_items) (void)hipFree(c->d_items);
     if (c->d_part_begin) (void)hipFree(c->d_part_begin);
     if (c->d_in) (void)hipFree(c->d_in);
-    if (c->d_lag) (void)hipFree(c->d_lag);
-    if (c->d_frac) (void)hipFree(c->d_frac);
-    if (c->d_peak) (void)hipFree(c->d_peak);
+    if (c->d_lag) (void)hipFree(c->d_lag);            // (d_frac / d_peak point into the same block)
+    if (c->h_out) (void)hipHostFree(c->h_out);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1650,6 +1650,46 @@ static float out_scale4096() {
     return std::ldexp(1.0f, 3 * kTw1ScaleLog2 - logl);
 }
 
+// host-pointer results: the three arrays live in ONE device block.  Small batches (the seam's one frequency group per
+// call) come back as ONE copy into pinned memory + three memcpys instead of three pageable copies (each of which the
+// runtime stages and synchronises on its own); large ones keep the three direct copies.
+static constexpr size_t kPackedOutMax = 256 * 1024;   // bytes of all three arrays
+static int ensure_out(rmx_ctx* c, size_t out_elems) {
+    if (c->d_out_elems >= out_elems) return RMX_OK;
+    if (c->d_lag) (void)hipFree(c->d_lag);
+    c->d_lag = nullptr; c->d_frac = nullptr; c->d_peak = nullptr; c->d_out_elems = 0;
+    const size_t stride = (out_elems + 63) & ~(size_t)63;           // 256-byte aligned sub-arrays
+    RMX_HIP(c, hipMalloc((void**)&c->d_lag, 3 * stride * sizeof(float)));
+    c->d_frac = reinterpret_cast<float*>(c->d_lag) + stride;
+    c->d_peak = c->d_frac + stride;
+    c->d_out_elems = out_elems;
+    return RMX_OK;
+}
+static int fetch_out(rmx_ctx* c, size_t out_elems, int32_t* lag_int, float* lag_frac, float* peak) {
+    const size_t nb = out_elems * sizeof(float);
+    const size_t span = (size_t)(reinterpret_cast<char*>(c->d_peak) - reinterpret_cast<char*>(c->d_lag)) + nb;
+    if (span <= kPackedOutMax) {
+        if (c->h_out_bytes < span) {
+            if (c->h_out) (void)hipHostFree(c->h_out);
+            c->h_out = nullptr; c->h_out_bytes = 0;
+            RMX_HIP(c, hipHostMalloc(&c->h_out, kPackedOutMax, hipHostMallocDefault));
+            c->h_out_bytes = kPackedOutMax;
+        }
+        RMX_HIP(c, hipMemcpyAsync(c->h_out, c->d_lag, span, hipMemcpyDeviceToHost, c->stream));
+        RMX_HIP(c, hipStreamSynchronize(c->stream));
+        const char* h = static_cast<const char*>(c->h_out);
+        std::memcpy(lag_int, h, nb);
+        std::memcpy(lag_frac, h + (reinterpret_cast<char*>(c->d_frac) - reinterpret_cast<char*>(c->d_lag)), nb);
+        std::memcpy(peak, h + (reinterpret_cast<char*>(c->d_peak) - reinterpret_cast<char*>(c->d_lag)), nb);
+        return RMX_OK;
+    }
+    RMX_HIP(c, hipMemcpyAsync(lag_int, c->d_lag, nb, hipMemcpyDeviceToHost, c->stream));
+    RMX_HIP(c, hipMemcpyAsync(lag_frac, c->d_frac, nb, hipMemcpyDeviceToHost, c->stream));
+    RMX_HIP(c, hipMemcpyAsync(peak, c->d_peak, nb, hipMemcpyDeviceToHost, c->stream));
+    RMX_HIP(c, hipStreamSynchronize(c->stream));
+    return RMX_OK;
+}
+
 // N = 4096, per-transform kernels: estimated us of k_fwd + the pair kernel for n_windows x n_pairs, and the pairs per
 // workgroup (1 ... 7, or the caller's) that minimise it -- the model of rmx_xcorr_batch's small-batch rule
 static double split_cost4096(const rmx_ctx* c, int n_windows, int n_pairs, int* ppb) {
@@ -1754,15 +1794,9 @@ int rmx_xcorr_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pa
     float* d_peak = peak;
     const size_t out_elems = (size_t)n_windows * n_pairs;
     if (!out_dev) {
-        if (c->d_out_elems < out_elems) {
-            if (c->d_lag) (void)hipFree(c->d_lag);
-            if (c->d_frac) (void)hipFree(c->d_frac);
-            if (c->d_peak) (void)hipFree(c->d_peak);
-            c->d_lag = nullptr; c->d_frac = nullptr; c->d_peak = nullptr; c->d_out_elems = 0;
-            RMX_HIP(c, hipMalloc((void**)&c->d_lag, out_elems * sizeof(int)));
-            RMX_HIP(c, hipMalloc((void**)&c->d_frac, out_elems * sizeof(float)));
-            RMX_HIP(c, hipMalloc((void**)&c->d_peak, out_elems * sizeof(float)));
-            c->d_out_elems = out_elems;
+        {
+            const int rc_out = ensure_out(c, out_elems);
+            if (rc_out != RMX_OK) return rc_out;
         }
         d_lag = c->d_lag; d_frac = c->d_frac; d_peak = c->d_peak;
     }
@@ -1770,12 +1804,7 @@ int rmx_xcorr_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pa
     if (c->generic) {
         rc = rmx::generic_batch(c, d_iq, n_windows, n_pairs, d_lag, d_frac, d_peak, u8);
         if (rc != RMX_OK) return rc;
-        if (!out_dev) {
-            RMX_HIP(c, hipMemcpyAsync(lag_int, d_lag, out_elems * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-            RMX_HIP(c, hipMemcpyAsync(lag_frac, d_frac, out_elems * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-            RMX_HIP(c, hipMemcpyAsync(peak, d_peak, out_elems * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-            RMX_HIP(c, hipStreamSynchronize(c->stream));
-        }
+        if (!out_dev) return fetch_out(c, out_elems, lag_int, lag_frac, peak);
         return RMX_OK;
     }
     const float out_scale = out_scale4096();   // (the forward scale 2^-6 rides on the TW1 table)
@@ -1864,12 +1893,7 @@ int rmx_xcorr_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pa
         rc = pairs4096(c, w0, wc, n_pairs, d_lag, d_frac, d_peak, out_scale, false);
         if (rc != RMX_OK) return rc;
     }
-    if (!out_dev) {
-        RMX_HIP(c, hipMemcpyAsync(lag_int, d_lag, out_elems * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        RMX_HIP(c, hipMemcpyAsync(lag_frac, d_frac, out_elems * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-        RMX_HIP(c, hipMemcpyAsync(peak, d_peak, out_elems * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-        RMX_HIP(c, hipStreamSynchronize(c->stream));
-    }
+    if (!out_dev) return fetch_out(c, out_elems, lag_int, lag_frac, peak);
     return RMX_OK;
 }
 
@@ -1942,15 +1966,9 @@ int rmx_caf_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pair
     int *b_dop = dop_idx, *b_lag = lag_int;
     float *b_frac = lag_frac, *b_peak = peak;
     if (!out_dev) {
-        if (c->d_out_elems < out_elems) {
-            if (c->d_lag) (void)hipFree(c->d_lag);
-            if (c->d_frac) (void)hipFree(c->d_frac);
-            if (c->d_peak) (void)hipFree(c->d_peak);
-            c->d_lag = nullptr; c->d_frac = nullptr; c->d_peak = nullptr; c->d_out_elems = 0;
-            RMX_HIP(c, hipMalloc((void**)&c->d_lag, out_elems * sizeof(int)));
-            RMX_HIP(c, hipMalloc((void**)&c->d_frac, out_elems * sizeof(float)));
-            RMX_HIP(c, hipMalloc((void**)&c->d_peak, out_elems * sizeof(float)));
-            c->d_out_elems = out_elems;
+        {
+            const int rc_out = ensure_out(c, out_elems);
+            if (rc_out != RMX_OK) return rc_out;
         }
         b_dop = c->caf_dop; b_lag = c->d_lag; b_frac = c->d_frac; b_peak = c->d_peak;
     }
