@@ -149,6 +149,7 @@ class TDoACalculator:
         self.device = device
         self.devices = devices
         self._engines: Dict[Tuple[int, int], Any] = {}   # insertion order = recency
+        self._tconf: Dict[Tuple[int, int], float] = {}
 
     # -- GPU engine cache ------------------------------------------------------------------------
     def _engine(self, n_buoys: int, n_samples: int, n_windows: int = 1):
@@ -258,8 +259,14 @@ class TDoACalculator:
             return None
 
     def _timing_confidence(self, b1: BuoyPosition, b2: BuoyPosition) -> float:
-        # exp(-rss(timing accuracies) / 100 us), capped at 1 (tdoa_processor.py:200-210)
-        return min(math.exp(-math.hypot(b1.timing_accuracy_ns, b2.timing_accuracy_ns) / 100000), 1.0)
+        # exp(-rss(timing accuracies) / 100 us), capped at 1 (tdoa_processor.py:200-210); a handful of distinct values
+        key = (b1.timing_accuracy_ns, b2.timing_accuracy_ns)
+        c = self._tconf.get(key)
+        if c is None:
+            if len(self._tconf) > 4096:
+                self._tconf.clear()
+            c = self._tconf[key] = min(math.exp(-math.hypot(key[0], key[1]) / 100000), 1.0)
+        return c
 
     _calculate_timing_confidence = _timing_confidence  # reference's private name
 
@@ -293,6 +300,11 @@ class TDoACalculator:
         elif _lag is not self._TIME_TAGS:
             lag, fs = _lag
         q = -1
+        if lag is not None:
+            # the same float64 arithmetic as `round(lag[q] / fs * 1e9)` per pair, done once for the group (numpy scalars make
+            # the pair loop four times slower than it needs to be; np.rint and round() both round half to even)
+            lag_ns = np.rint(np.asarray(lag, np.float64) / fs * 1e9).astype(np.int64).tolist()
+        debug = self.logger.isEnabledFor(logging.DEBUG)
         for i in range(nd):
             for j in range(i + 1, nd):
                 q += 1
@@ -301,15 +313,15 @@ class TDoACalculator:
                     continue
                 dt_ns = d2.gps_timestamp_ns - d1.gps_timestamp_ns
                 if lag is not None:
-                    dt_ns += int(round(lag[q] / fs * 1e9))
+                    dt_ns += lag_ns[q]
                 dist_m = dt_ns / 1e9 * self.SPEED_OF_LIGHT
                 p1, p2 = buoy_positions.get(d1.buoy_id), buoy_positions.get(d2.buoy_id)
                 if not p1 or not p2:
                     continue
                 conf = min(d1.confidence, d2.confidence) * self._timing_confidence(p1, p2)
                 out.append(TDoAMeasurement(d1.buoy_id, d2.buoy_id, dt_ns, dist_m, conf, d1.frequency_mhz))
-                self.logger.debug("TDoA %s-%s dT=%.1f us dD=%.1f m", d1.buoy_id, d2.buoy_id,
-                                  dt_ns / 1000, dist_m)
+                if debug:
+                    self.logger.debug("TDoA %s-%s dT=%.1f us dD=%.1f m", d1.buoy_id, d2.buoy_id, dt_ns / 1000, dist_m)
         return out
 
 
