@@ -23,8 +23,8 @@
  *         d   = 3-point parabolic vertex offset      lag_frac = d  (0 at the edges / flat top)
  *               (d = (a - c) / (2 (a - 2b + c)) in double precision from the float32 taps a, b, c = m[k-1], m[k], m[k+1].
  *               Against another float32 implementation of the same definition it agrees to 1e-5 * max(|lag|, 1)
- *               wherever that formula is well conditioned -- 3.9 M random pair-windows, N = 16 ... 2^18, worst 7e-6 --
- *               and to the formula's own conditioning where it is not: one pair-window of those, a flat peak on a
+ *               wherever that formula is well conditioned -- 8.7 M random pair-windows, N = 16 ... 2^18, worst 7e-6 --
+ *               and to the formula's own conditioning where it is not: two pair-windows of those, e.g. a flat peak on a
  *               32-sample window at 0 dB (a - 2b + c = 4e-3 b), where one float32 ulp on each tap moves d by 2.3e-5,
  *               differed by 3.3e-5: tools/soak_parity.py.)
  *         peak = m[k]
