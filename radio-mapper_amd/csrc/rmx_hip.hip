@@ -46,13 +46,16 @@ template <bool U8>
 __global__ __launch_bounds__(kThreads, 4) void k_fwd(const void* __restrict__ iq_v, float4* __restrict__ spec,
                                                      const float4* __restrict__ tw1_g,
                                                      const float2* __restrict__ tw2_g, long first_item,
-                                                     float scale, const float2* __restrict__ rot) {
+                                                     float scale, const float2* __restrict__ rot, int wrap_items) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2* xl = reinterpret_cast<float2*>(smem);
     float2* tw2_lds = reinterpret_cast<float2*>(smem + kLdsXchg);
     const int t = threadIdx.x;
     const int p = t & 1, u = t >> 1;
-    const long item = first_item + blockIdx.x;
+    // wrap_items > 0 (rmx_caf_batch, all hypotheses in one launch): workgroup b transforms real item b % wrap_items
+    // de-rotated by hypothesis b / wrap_items; its spectrum still goes to slot b
+    const long item = first_item + (wrap_items > 0 ? (long)(blockIdx.x % (unsigned)wrap_items) : (long)blockIdx.x);
+    if (wrap_items > 0 && rot) rot += (size_t)(blockIdx.x / (unsigned)wrap_items) * kM;
 
     load_tw2_to_lds(tw2_lds, tw2_g, t);
     float2 tw1[16];
@@ -109,7 +112,7 @@ __device__ __forceinline__ void pair_body(const float4* __restrict__ spec, const
                                           const int* __restrict__ part_begin, int n_parts, int n_buoys,
                                           int n_pairs, int xcd_map, long first_window, float out_scale,
                                           int* __restrict__ lag_int, float* __restrict__ lag_frac,
-                                          float* __restrict__ peak) {
+                                          float* __restrict__ peak, int i_wrap) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2* xl = reinterpret_cast<float2*>(smem);
     float2* tw2_lds = reinterpret_cast<float2*>(smem + kLdsXchg);
@@ -144,10 +147,11 @@ __device__ __forceinline__ void pair_body(const float4* __restrict__ spec, const
     const int it_begin = part_begin[part];
     const int it_end = part_begin[part + 1];
     const long wbase = (long)wl * n_buoys;
+    const long wbase_i = (long)(i_wrap > 0 ? wl % i_wrap : wl) * n_buoys;   // (rmx_caf_batch: wl = hypothesis * windows + window)
     float4 sa[8], sb[8];   // X_i (anchor) and X_j of the pair about to be processed
     PairItem pi = items[it_begin < it_end ? it_begin : 0];
     if (it_begin < it_end) {
-        const float4* xi = spec + (wbase + pi.i) * (8 * kThreads);
+        const float4* xi = spec + (wbase_i + pi.i) * (8 * kThreads);
         const float4* xj = spec_j + (wbase + pi.j) * (8 * kThreads);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -201,7 +205,7 @@ __device__ __forceinline__ void pair_body(const float4* __restrict__ spec, const
         {
             if (it + 1 < it_end) {
                 pi = items[it + 1];
-                const float4* xi = spec + (wbase + pi.i) * (8 * kThreads);
+                const float4* xi = spec + (wbase_i + pi.i) * (8 * kThreads);
                 const float4* xj = spec_j + (wbase + pi.j) * (8 * kThreads);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -318,7 +322,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_pair_res(
     const float4* __restrict__ spec, const float4* __restrict__ spec_j, const float4* __restrict__ tw1_g, const float2* __restrict__ tw2_g,
     const PairItem* __restrict__ items, const int* __restrict__ part_begin, int n_parts, int n_buoys, int n_pairs,
     int xcd_map, long first_window, float out_scale, int* __restrict__ lag_int, float* __restrict__ lag_frac,
-    float* __restrict__ peak, int dbg_rt) {
+    float* __restrict__ peak, int dbg_rt, int i_wrap) {
 #ifdef RMX_ABLATE
     const int dbg = dbg_rt;   // timing-only ablation build (wrong results), as in k_win
 #else
@@ -357,12 +361,13 @@ __global__ __launch_bounds__(kThreads, 2) void k_pair_res(
     const int it_end = part_begin[part + 1];
     if (it_begin >= it_end) return;
     const long wbase = (long)wl * n_buoys;
+    const long wbase_i = (long)(i_wrap > 0 ? wl % i_wrap : wl) * n_buoys;   // (rmx_caf_batch: wl = hypothesis * windows + window)
     const long obase = (first_window + wl) * (long)n_pairs;
     float4 sa[8], sb[8];
     PairItem pi = items[it_begin];
     int cur_i = pi.i;
     {
-        const float4* xi = spec + (wbase + pi.i) * (8 * kThreads);
+        const float4* xi = spec + (wbase_i + pi.i) * (8 * kThreads);
         const float4* xj = spec_j + (wbase + pi.j) * (8 * kThreads);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -389,7 +394,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_pair_res(
             for (int j = 0; j < 8; ++j) sb[j] = xj[j * kThreads + t];
             if (pi.i != cur_i) {
                 cur_i = pi.i;
-                const float4* xi = spec + (wbase + pi.i) * (8 * kThreads);
+                const float4* xi = spec + (wbase_i + pi.i) * (8 * kThreads);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) sa[j] = xi[j * kThreads + t];
             }
@@ -472,10 +477,10 @@ __global__ __launch_bounds__(kThreads, 2) void k_winp(const void* __restrict__ i
         const float2 *__restrict__ tw2_g,                                                                     \
         const PairItem *__restrict__ items, const int *__restrict__ part_begin, int n_parts, int n_buoys,     \
         int n_pairs, int xcd_map, long first_window, float out_scale, int *__restrict__ lag_int,              \
-        float *__restrict__ lag_frac, float *__restrict__ peak
+        float *__restrict__ lag_frac, float *__restrict__ peak, int i_wrap
 #define RMX_PAIR_PASS                                                                                         \
     spec, spec_j, tw1_g, tw2_g, items, part_begin, n_parts, n_buoys, n_pairs, xcd_map, first_window, out_scale,      \
-        lag_int, lag_frac, peak
+        lag_int, lag_frac, peak, i_wrap
 
 __global__ __launch_bounds__(kThreads, 4) void k_pair_str(RMX_PAIR_ARGS) { pair_body(RMX_PAIR_PASS); }
 
@@ -489,6 +494,22 @@ __global__ void k_caf_select(int d, long first, long n, const int* __restrict__ 
     if (d == 0 || peak_d[i] > peak[i]) {   // strict: ties keep the lowest d
         dop[i] = d; lag[i] = lag_d[i]; frac[i] = frac_d[i]; peak[i] = peak_d[i];
     }
+}
+
+
+// the same over all hypotheses of one launch: arrays [n_dop][n], d-major first maximum (strict >: ties keep the lowest d)
+__global__ void k_caf_select_all(int n_dop, long n, const int* __restrict__ lag_d, const float* __restrict__ frac_d,
+                                 const float* __restrict__ peak_d, int* __restrict__ dop, int* __restrict__ lag,
+                                 float* __restrict__ frac, float* __restrict__ peak) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int bd = 0;
+    float bp = peak_d[i];
+    for (int d = 1; d < n_dop; ++d) {
+        const float pd = peak_d[(long)d * n + i];
+        if (pd > bp) { bp = pd; bd = d; }
+    }
+    dop[i] = bd; lag[i] = lag_d[(long)bd * n + i]; frac[i] = frac_d[(long)bd * n + i]; peak[i] = bp;
 }
 
 
@@ -631,6 +652,7 @@ struct rmx_ctx {
     int* d_part_begin = nullptr;
     void* d_in = nullptr;      size_t d_in_bytes = 0;
     int* d_lag = nullptr;      float* d_frac = nullptr;  float* d_peak = nullptr;  size_t d_out_elems = 0;   // ONE block: lag | frac | peak
+    int* d_dop = nullptr;
     void* h_out = nullptr;     size_t h_out_bytes = 0;   // pinned staging of small host-pointer results (fetch_out)
     size_t spec_bytes = 0, scratch_bytes = 0;
     // generic path (n_samples != 4096): see generic_path.hpp
@@ -1590,11 +1612,13 @@ static int ensure_spec(rmx_ctx* c, long windows) {
 
 // N = 4096, unfused path: forward spectra of windows [w0, w0 + wc) into d_spec (rot == nullptr) or, de-rotated by
 // the phasor table rot[N], into d_spec_r (rmx_caf_batch); then the pair kernels over the plan's pair list
-static int fwd4096(rmx_ctx* c, const void* d_iq, int w0, int wc, bool u8, const float2* rot) {
+static int fwd4096(rmx_ctx* c, const void* d_iq, int w0, int wc, bool u8, const float2* rot, int n_bins = 1) {
     const long first_item = (long)w0 * c->n_buoys;
-    const int n_items = wc * c->n_buoys;
+    const int wrap = n_bins > 1 ? wc * c->n_buoys : 0;
+    const int n_items = wc * c->n_buoys * n_bins;
     if (rot) {
-        const size_t nb = (size_t)(wc < c->chunk_windows ? c->chunk_windows : wc) * c->n_buoys * (8 * kThreads) * sizeof(float4);
+        const size_t nb = n_bins > 1 ? (size_t)n_items * (8 * kThreads) * sizeof(float4)
+                                     : (size_t)(wc < c->chunk_windows ? c->chunk_windows : wc) * c->n_buoys * (8 * kThreads) * sizeof(float4);
         if (c->spec_r_bytes < nb) {
             RMX_HIP(c, hipStreamSynchronize(c->stream));
             if (c->d_spec_r) (void)hipFree(c->d_spec_r);
@@ -1608,10 +1632,10 @@ static int fwd4096(rmx_ctx* c, const void* d_iq, int w0, int wc, bool u8, const 
     if (c->timing) RMX_HIP(c, hipEventRecord(c->ev[c->ev_used], c->stream));
     if (u8)
         hipLaunchKernelGGL(k_fwd<true>, dim3(n_items), dim3(kThreads), kLdsBytes, c->stream, d_iq, dst, c->d_tw1, c->d_tw2,
-                           first_item, 1.0f, rot);
+                           first_item, 1.0f, rot, wrap);
     else
         hipLaunchKernelGGL(k_fwd<false>, dim3(n_items), dim3(kThreads), kLdsBytes, c->stream, d_iq, dst, c->d_tw1, c->d_tw2,
-                           first_item, 1.0f, rot);
+                           first_item, 1.0f, rot, wrap);
     RMX_HIP(c, hipGetLastError());
     if (c->timing) {
         RMX_HIP(c, hipEventRecord(c->ev[c->ev_used + 1], c->stream));
@@ -1621,19 +1645,21 @@ static int fwd4096(rmx_ctx* c, const void* d_iq, int w0, int wc, bool u8, const 
     return RMX_OK;
 }
 static int pairs4096(rmx_ctx* c, int w0, int wc, int n_pairs, int* d_lag, float* d_frac, float* d_peak, float out_scale,
-                     bool use_rot) {
+                     bool use_rot, int n_bins = 1) {
     const int n_parts = c->plan_n_parts;
+    const int i_wrap = n_bins > 1 ? wc : 0;     // (all hypotheses in one launch: virtual window = hypothesis * wc + window)
+    wc *= n_bins;
     const int xcd_map = (wc % 8 == 0) ? 1 : 0;
     const float4* spec_j = use_rot ? c->d_spec_r : c->d_spec;
     if (c->timing) RMX_HIP(c, hipEventRecord(c->ev[c->ev_used], c->stream));
     if (c->resident)
         hipLaunchKernelGGL(k_pair_res, dim3(wc * n_parts), dim3(kThreads), kLdsResBytes, c->stream, (const float4*)c->d_spec,
                            spec_j, c->d_tw1, c->d_tw2, c->d_items, c->d_part_begin, n_parts, c->n_buoys, n_pairs, xcd_map,
-                           (long)w0, out_scale, d_lag, d_frac, d_peak, c->dbg);
+                           (long)w0, out_scale, d_lag, d_frac, d_peak, c->dbg, i_wrap);
     else
         hipLaunchKernelGGL(k_pair_str, dim3(wc * n_parts), dim3(kThreads), kLdsBytes, c->stream, (const float4*)c->d_spec, spec_j,
                            c->d_tw1, c->d_tw2, c->d_items, c->d_part_begin, n_parts, c->n_buoys, n_pairs, xcd_map, (long)w0,
-                           out_scale, d_lag, d_frac, d_peak);
+                           out_scale, d_lag, d_frac, d_peak, i_wrap);
     RMX_HIP(c, hipGetLastError());
     if (c->timing) {
         RMX_HIP(c, hipEventRecord(c->ev[c->ev_used + 1], c->stream));
@@ -1659,15 +1685,17 @@ static int ensure_out(rmx_ctx* c, size_t out_elems) {
     if (c->d_lag) (void)hipFree(c->d_lag);
     c->d_lag = nullptr; c->d_frac = nullptr; c->d_peak = nullptr; c->d_out_elems = 0;
     const size_t stride = (out_elems + 63) & ~(size_t)63;           // 256-byte aligned sub-arrays
-    RMX_HIP(c, hipMalloc((void**)&c->d_lag, 3 * stride * sizeof(float)));
+    RMX_HIP(c, hipMalloc((void**)&c->d_lag, 4 * stride * sizeof(float)));
     c->d_frac = reinterpret_cast<float*>(c->d_lag) + stride;
     c->d_peak = c->d_frac + stride;
+    c->d_dop = reinterpret_cast<int*>(c->d_peak + stride);     // (rmx_caf_batch's fourth array)
     c->d_out_elems = out_elems;
     return RMX_OK;
 }
-static int fetch_out(rmx_ctx* c, size_t out_elems, int32_t* lag_int, float* lag_frac, float* peak) {
+static int fetch_out(rmx_ctx* c, size_t out_elems, int32_t* lag_int, float* lag_frac, float* peak, int32_t* dop = nullptr) {
     const size_t nb = out_elems * sizeof(float);
-    const size_t span = (size_t)(reinterpret_cast<char*>(c->d_peak) - reinterpret_cast<char*>(c->d_lag)) + nb;
+    const char* last = reinterpret_cast<char*>(dop ? (void*)c->d_dop : (void*)c->d_peak);
+    const size_t span = (size_t)(last - reinterpret_cast<char*>(c->d_lag)) + nb;
     if (span <= kPackedOutMax) {
         if (c->h_out_bytes < span) {
             if (c->h_out) (void)hipHostFree(c->h_out);
@@ -1681,8 +1709,10 @@ static int fetch_out(rmx_ctx* c, size_t out_elems, int32_t* lag_int, float* lag_
         std::memcpy(lag_int, h, nb);
         std::memcpy(lag_frac, h + (reinterpret_cast<char*>(c->d_frac) - reinterpret_cast<char*>(c->d_lag)), nb);
         std::memcpy(peak, h + (reinterpret_cast<char*>(c->d_peak) - reinterpret_cast<char*>(c->d_lag)), nb);
+        if (dop) std::memcpy(dop, h + (reinterpret_cast<char*>(c->d_dop) - reinterpret_cast<char*>(c->d_lag)), nb);
         return RMX_OK;
     }
+    if (dop) RMX_HIP(c, hipMemcpyAsync(dop, c->d_dop, nb, hipMemcpyDeviceToHost, c->stream));
     RMX_HIP(c, hipMemcpyAsync(lag_int, c->d_lag, nb, hipMemcpyDeviceToHost, c->stream));
     RMX_HIP(c, hipMemcpyAsync(lag_frac, c->d_frac, nb, hipMemcpyDeviceToHost, c->stream));
     RMX_HIP(c, hipMemcpyAsync(peak, c->d_peak, nb, hipMemcpyDeviceToHost, c->stream));
@@ -1915,9 +1945,14 @@ int rmx_caf_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pair
     if (n_pairs < 0) return fail(c, RMX_E_INVAL, "n_pairs %d < 0", n_pairs);
     if (n_windows == 0 || n_pairs == 0) return RMX_OK;
     RMX_HIP(c, hipSetDevice(c->device));
+    // N = 4096, one chunk: all hypotheses in ONE forward launch and ONE pair launch (virtual window = hypothesis x
+    // window) instead of three launches per hypothesis -- 21 hypotheses on one frequency group: 431 -> ~60 us
+    const bool batch_bins = !c->generic && n_dopplers > 1 && n_windows <= c->chunk_windows &&
+                            (size_t)n_dopplers * n_windows * B * (8 * kThreads) * sizeof(float4) <= ((size_t)1 << 30) &&
+                            (long)n_dopplers * n_windows < (1L << 20);
     if (!c->generic && !c->ppb_user) {               // (N = 4096: blocks sized to this batch, not to the previous call's)
         int q = 7;
-        (void)split_cost4096(c, n_windows, n_pairs, &q);
+        (void)split_cost4096(c, batch_bins ? n_windows * n_dopplers : n_windows, n_pairs, &q);
         c->pairs_per_block = q;
     }
     int rc = build_plan(c, pairs, n_pairs);          // validates the pair list
@@ -1953,15 +1988,15 @@ int rmx_caf_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pair
         c->caf_grid = grid;
     }
     const size_t out_elems = (size_t)n_windows * n_pairs;
-    if (c->caf_out_elems < out_elems) {
+    const size_t caf_elems = batch_bins ? out_elems * (size_t)n_dopplers : out_elems;   // per-hypothesis results: [d][w][pair]
+    if (c->caf_out_elems < caf_elems) {
         for (void* p : {(void*)c->caf_lag, (void*)c->caf_frac, (void*)c->caf_peak, (void*)c->caf_dop})
             if (p) (void)hipFree(p);
         c->caf_lag = nullptr; c->caf_frac = nullptr; c->caf_peak = nullptr; c->caf_dop = nullptr; c->caf_out_elems = 0;
-        RMX_HIP(c, hipMalloc((void**)&c->caf_lag, out_elems * sizeof(int)));
-        RMX_HIP(c, hipMalloc((void**)&c->caf_frac, out_elems * sizeof(float)));
-        RMX_HIP(c, hipMalloc((void**)&c->caf_peak, out_elems * sizeof(float)));
-        RMX_HIP(c, hipMalloc((void**)&c->caf_dop, out_elems * sizeof(int)));
-        c->caf_out_elems = out_elems;
+        RMX_HIP(c, hipMalloc((void**)&c->caf_lag, caf_elems * sizeof(int)));
+        RMX_HIP(c, hipMalloc((void**)&c->caf_frac, caf_elems * sizeof(float)));
+        RMX_HIP(c, hipMalloc((void**)&c->caf_peak, caf_elems * sizeof(float)));
+        c->caf_out_elems = caf_elems;
     }
     int *b_dop = dop_idx, *b_lag = lag_int;
     float *b_frac = lag_frac, *b_peak = peak;
@@ -1970,7 +2005,7 @@ int rmx_caf_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pair
             const int rc_out = ensure_out(c, out_elems);
             if (rc_out != RMX_OK) return rc_out;
         }
-        b_dop = c->caf_dop; b_lag = c->d_lag; b_frac = c->d_frac; b_peak = c->d_peak;
+        b_dop = c->d_dop; b_lag = c->d_lag; b_frac = c->d_frac; b_peak = c->d_peak;
     }
     // Per chunk of windows: the un-rotated spectra once, then per hypothesis the de-rotated spectra (the rotation
     // is applied as the window is loaded), the pair kernels with X_i un-rotated and X_j de-rotated, and the
@@ -1988,7 +2023,17 @@ int rmx_caf_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pair
         if (rc != RMX_OK) { c->timing = timing; return rc; }
     }
     const float osc = out_scale4096();
-    for (int w0 = 0; w0 < n_windows && rc == RMX_OK; w0 += chunk) {
+    if (batch_bins) {
+        rc = fwd4096(c, d_iq, 0, n_windows, u8, nullptr);
+        if (rc == RMX_OK) rc = fwd4096(c, d_iq, 0, n_windows, u8, c->caf_rot, n_dopplers);
+        if (rc == RMX_OK) rc = pairs4096(c, 0, n_windows, n_pairs, c->caf_lag, c->caf_frac, c->caf_peak, osc, true, n_dopplers);
+        if (rc == RMX_OK) {
+            hipLaunchKernelGGL(k_caf_select_all, dim3((unsigned)((out_elems + 255) / 256)), dim3(256), 0, c->stream, n_dopplers,
+                               (long)out_elems, c->caf_lag, c->caf_frac, c->caf_peak, b_dop, b_lag, b_frac, b_peak);
+            if (hipGetLastError() != hipSuccess) rc = fail(c, RMX_E_HIP, "k_caf_select_all launch failed");
+        }
+    }
+    for (int w0 = 0; !batch_bins && w0 < n_windows && rc == RMX_OK; w0 += chunk) {
         const int wc = n_windows - w0 < chunk ? n_windows - w0 : chunk;
         rc = c->generic ? rmx::generic_forward(c, d_iq, w0, wc, u8, nullptr) : fwd4096(c, d_iq, w0, wc, u8, nullptr);
         for (int d = 0; d < n_dopplers && rc == RMX_OK; ++d) {
@@ -2006,13 +2051,7 @@ int rmx_caf_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pair
     }
     c->timing = timing;
     if (rc != RMX_OK) return rc;
-    if (!out_dev) {
-        RMX_HIP(c, hipMemcpyAsync(dop_idx, b_dop, out_elems * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        RMX_HIP(c, hipMemcpyAsync(lag_int, b_lag, out_elems * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        RMX_HIP(c, hipMemcpyAsync(lag_frac, b_frac, out_elems * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-        RMX_HIP(c, hipMemcpyAsync(peak, b_peak, out_elems * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-        RMX_HIP(c, hipStreamSynchronize(c->stream));
-    }
+    if (!out_dev) return fetch_out(c, out_elems, lag_int, lag_frac, peak, dop_idx);
     return RMX_OK;
 }
 

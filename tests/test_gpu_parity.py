@@ -833,3 +833,35 @@ def test_partial_last_round_goes_through_the_per_transform_kernels(xc, opts):
         k = (W // n_cus) * n_cus                      # the full rounds are the same kernel on the same data
         for a, b in zip(got, fused):
             assert np.array_equal(a[:k], b[:k])
+
+
+def test_caf_all_hypotheses_in_one_launch(xc):
+    """N = 4096, one chunk: rmx_caf_batch runs every hypothesis in one forward and one pair launch (virtual window =
+    hypothesis x window).  Against the oracle's per-hypothesis loop on 8 buoys x 3 windows x 21 hypotheses with true offsets
+    inside the grid, complex64 and uint8, default and custom pair list; a differing Doppler row is accepted only when the
+    oracle's own peak in that row is within 1e-5 of its best."""
+    B, W, N, D = 8, 3, 4096, 21
+    fs = 2.4e6
+    grid = (np.arange(D) - D // 2) * 50.0 / fs
+    rng = np.random.default_rng(5)
+    true = rng.uniform(-400.0, 400.0, size=(W, B)) / fs
+    out = rm.synth.make_windows(W, B, N, fs, seed=2024, return_u8=True, doppler_cps=true)
+    iq, raw = out[0], out[2]
+    sel = np.array([[0, 7], [3, 1], [2, 6], [6, 2]], np.int32)
+    with xc.XcorrEngine(B, N, W) as eng:
+        for pairs in (None, sel):
+            rd, ri, rf, rp = orc.caf_batch(iq, grid, pairs)
+            gd, li, lf, pk = eng.caf(iq, grid, pairs)
+            gd8, li8, lf8, pk8 = eng.caf(raw, grid, pairs)
+            assert np.array_equal(gd, gd8) and np.array_equal(li, li8) and np.array_equal(lf, lf8) and np.array_equal(pk, pk8)
+            plist = orc.pair_list(B) if pairs is None else pairs
+            for w, q in zip(*np.nonzero((gd != rd) | (li != ri))):
+                i, j = int(plist[q, 0]), int(plist[q, 1])
+                y = (iq[w, j] * orc.doppler_phasor(grid[gd[w, q]], N)).astype(np.complex64)
+                alt = orc.xcorr_pair(iq[w, i], y)[2]
+                assert abs(float(alt) - float(rp[w, q])) <= 1e-5 * float(rp[w, q]), (w, q)
+            same = (gd == rd) & (li == ri)
+            assert same.mean() > 0.95
+            ref = (ri + rf)[same]
+            assert np.all(np.abs((li + lf.astype(np.float64))[same] - ref) <= TOL * np.maximum(np.abs(ref), 1.0))
+            assert np.allclose(pk[same], rp[same], rtol=1e-5)
