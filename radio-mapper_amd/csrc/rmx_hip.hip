@@ -1786,7 +1786,16 @@ int rmx_xcorr_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pa
             ppb_small = q;
         }
     }
-    if (!c->generic && !c->ppb_user) c->pairs_per_block = (small || tail) ? ppb_small : 7;
+    if (!c->generic && !c->ppb_user) {
+        if (!small && !tail && (pairs != nullptr || !c->fused)) {   // a custom pair list (or fused = 0): the per-transform kernels anyway
+            int q = 7;
+            (void)split_cost4096(c, n_windows, n_pairs, &q);
+            ppb_small = q;
+            c->pairs_per_block = q;
+        } else {
+            c->pairs_per_block = (small || tail) ? ppb_small : 7;
+        }
+    }
     int rc = build_plan(c, pairs, n_pairs);
     if (rc != RMX_OK) return rc;
     const bool fused_now = c->fused && c->plan_all_pairs && !small;
