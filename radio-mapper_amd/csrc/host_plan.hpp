@@ -4,6 +4,7 @@
 // section 5 asks for on the CPU side of the boundary.
 #pragma once
 #include <climits>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -176,6 +177,35 @@ inline long generic_chunk_windows(int n_buoys, long L, int max_windows, long bud
     if (chunk > 4096) chunk = 4096;
     if (cap >= 1 && cap < chunk) chunk = cap;
     return chunk;
+}
+
+// ---- N = 4096: fused kernel or per-transform kernels, and how many pairs per workgroup -----------------------------
+// Estimated microseconds, fitted to tools/exp_small4096.py on MI355X: 2.6 per transform of the
+// fused kernel (one workgroup per window, a round = one window on every CU); 3.5 per round of forward workgroups (two per
+// CU); 4.0 per pair workgroup + 3.3 per pair in it (one per CU); a round that fills the chip runs up to 45 % slower than
+// a lone workgroup, less so when many rounds follow each other out of step.
+inline double fused_cost4096(int n_cus, int n_buoys, int n_pairs, long n_windows) {
+    const long cus = n_cus > 0 ? n_cus : 1;
+    return (double)((n_windows + cus - 1) / cus) * (n_buoys + n_pairs) * 2.6 + 3.0;
+}
+// the per-transform estimate and the pairs per workgroup (1 ... 7, or `fixed_ppb` when the caller set them) that minimise it
+inline double split_cost4096(int n_cus, int n_buoys, int n_pairs, long n_windows, int fixed_ppb, int* ppb) {
+    const long cus = n_cus > 0 ? n_cus : 1;
+    auto rounds = [](long blocks, long per_round) { return (double)((blocks + per_round - 1) / per_round); };
+    const double t_fwd = rounds(n_windows * n_buoys, 2 * cus) * 3.5 + 2.0;
+    double best = 1e30;
+    *ppb = fixed_ppb > 0 ? fixed_ppb : 7;
+    for (int q = 7; q >= 1; --q) {
+        const int qq = fixed_ppb > 0 ? fixed_ppb : q;
+        const long parts = n_pairs > 0 ? (n_pairs + qq - 1) / qq : 1;
+        const long blocks = n_windows * parts;
+        const double r = blocks > 0 ? rounds(blocks, cus) : 1.0;
+        const double fill = blocks >= cus ? 1.0 : (double)blocks / (double)cus;
+        const double t = (t_fwd + r * (4.0 + 3.3 * (double)((n_pairs + parts - 1) / parts))) * (1.15 + 0.3 * fill / std::sqrt(r));
+        if (t < best) { best = t; *ppb = qq; }
+        if (fixed_ppb > 0) break;
+    }
+    return best;
 }
 
 }  // namespace host

@@ -1720,24 +1720,9 @@ static int fetch_out(rmx_ctx* c, size_t out_elems, int32_t* lag_int, float* lag_
     return RMX_OK;
 }
 
-// N = 4096, per-transform kernels: estimated us of k_fwd + the pair kernel for n_windows x n_pairs, and the pairs per
-// workgroup (1 ... 7, or the caller's) that minimise it -- the model of rmx_xcorr_batch's small-batch rule
+// N = 4096: the model of host_plan.hpp with this ctx's numbers
 static double split_cost4096(const rmx_ctx* c, int n_windows, int n_pairs, int* ppb) {
-    const long cus = c->n_cus > 0 ? c->n_cus : 1;
-    auto rounds = [&](long blocks, long per_round) { return (double)((blocks + per_round - 1) / per_round); };
-    const double t_fwd = rounds((long)n_windows * c->n_buoys, 2 * cus) * 3.5 + 2.0;
-    double best = 1e30;
-    for (int q = 7; q >= 1; --q) {
-        const int qq = c->ppb_user ? c->pairs_per_block : q;
-        const long parts = (n_pairs + qq - 1) / qq;
-        const long blocks = (long)n_windows * parts;
-        const double r = rounds(blocks, cus);
-        const double fill = blocks >= cus ? 1.0 : (double)blocks / (double)cus;
-        const double t = (t_fwd + r * (4.0 + 3.3 * ((n_pairs + parts - 1) / parts))) * (1.15 + 0.3 * fill / std::sqrt(r));
-        if (t < best) { best = t; *ppb = qq; }
-        if (c->ppb_user) break;
-    }
-    return best;
+    return host::split_cost4096(c->n_cus, c->n_buoys, n_pairs, n_windows, c->ppb_user ? c->pairs_per_block : 0, ppb);
 }
 
 int rmx_xcorr_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pairs, int n_pairs,
@@ -1768,9 +1753,7 @@ int rmx_xcorr_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pa
     bool small = false;
     int ppb_small = 7;
     if (!c->generic && c->fused && c->small_batch && c->n_buoys >= 3 && n_pairs == all_pairs) {
-        const long cus = c->n_cus > 0 ? c->n_cus : 1;
-        const double t_fused = (double)((n_windows + cus - 1) / cus) * (c->n_buoys + n_pairs) * 2.6 + 3.0;
-        small = split_cost4096(c, n_windows, n_pairs, &ppb_small) < t_fused;
+        small = split_cost4096(c, n_windows, n_pairs, &ppb_small) < host::fused_cost4096(c->n_cus, c->n_buoys, n_pairs, n_windows);
     }
     const bool in_dev = flags & RMX_IN_DEVICE, out_dev = flags & RMX_OUT_DEVICE, u8 = flags & RMX_IN_U8;
     // The same arithmetic for the LAST round of a larger batch: W = k CUs + r windows cost the fused kernel k + 1 rounds
@@ -1781,7 +1764,7 @@ int rmx_xcorr_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pa
         n_windows > c->n_cus && n_windows % c->n_cus != 0 && (in_dev || n_windows <= kHostSubChunk)) {
         int q = 7;
         const int r = n_windows % c->n_cus;
-        if (split_cost4096(c, r, n_pairs, &q) < 0.9 * ((c->n_buoys + n_pairs) * 2.6 + 3.0)) {
+        if (split_cost4096(c, r, n_pairs, &q) < 0.9 * host::fused_cost4096(c->n_cus, c->n_buoys, n_pairs, 1)) {
             tail = r;
             ppb_small = q;
         }

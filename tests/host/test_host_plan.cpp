@@ -107,6 +107,25 @@ static void test_pair_plan() {
 
 static void test_chunks() {
     // cfg2: 3 buoys, L = 2^21, 64 windows -> one chunk; the cap and the 4096 limit; never below one window
+    {   // the N = 4096 dispatch model: the measured crossovers of tools/exp_small4096.py, and no way to break it
+        int q = 0;
+        CHECK(split_cost4096(256, 8, 28, 1, 0, &q) < fused_cost4096(256, 8, 28, 1) && q == 1);        // one group: per-transform, 1 pair per block
+        CHECK(split_cost4096(256, 16, 120, 1, 0, &q) < fused_cost4096(256, 16, 120, 1) && q == 1);
+        CHECK(split_cost4096(256, 8, 28, 64, 0, &q) < fused_cost4096(256, 8, 28, 64) && q == 7);      // 64 windows: 7 pairs per block
+        CHECK(split_cost4096(256, 8, 28, 256, 0, &q) > fused_cost4096(256, 8, 28, 256));              // a full round: fused
+        CHECK(split_cost4096(256, 3, 3, 128, 0, &q) > fused_cost4096(256, 3, 3, 128));
+        CHECK(split_cost4096(256, 3, 3, 32, 0, &q) < fused_cost4096(256, 3, 3, 32));
+        CHECK(split_cost4096(256, 8, 28, 4, 5, &q) > 0 && q == 5);                                    // the caller's block size is kept
+        for (int cus : {0, 1, 7, 256, 4096})
+            for (long w : {0L, 1L, 255L, 256L, 257L, 1L << 20})
+                for (int b : {2, 3, 64})
+                    for (int fixed : {0, 1, 1 << 20}) {
+                        const int pairs = b * (b - 1) / 2;
+                        const double t = split_cost4096(cus, b, pairs, w, fixed, &q), f = fused_cost4096(cus, b, pairs, w);
+                        CHECK(t > 0 && t < 1e30 && f > 0 && q >= 1 && (fixed ? q == fixed : q <= 7));
+                    }
+        CHECK(split_cost4096(256, 4, 0, 3, 0, &q) > 0 && q >= 1);                                     // an empty pair list divides by nothing
+    }
     CHECK(generic_chunk_windows(3, 1L << 21, 64, 32L << 30, 0) == 64);
     CHECK(generic_chunk_windows(3, 1L << 21, 64, 32L << 30, 16) == 16);
     CHECK(generic_chunk_windows(32, 1L << 19, 64, 32L << 30, 0) == (32L << 30) / ((32 + 496) * (1L << 19) * 8));
