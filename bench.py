@@ -439,6 +439,20 @@ def main():
                       "lags_within_1_sample_of_truth": truth_ok}
         if n_gpus == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(host_windows, W, B, N, args.cpu_budget, doppler=grid)
+        # latency of ONE window of the same shape (the reference's call pattern: one frequency group per call), device
+        # pointers, outside the timed region; extra information, not part of the metric
+        single = None
+        if not caf:
+            eng.set_option("timing", 0)
+            one = lambda: eng.correlate_device(x.data_ptr(), 1, lag.data_ptr(), frac.data_ptr(), peak.data_ptr())
+            for _ in range(20):
+                one()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(200):
+                one()
+            torch.cuda.synchronize()
+            single = {"windows": 1, "us_per_call": (time.perf_counter() - t0) / 200 * 1e6}
 
     if rank == 0:
         units_per_step = W_total * P * N * D                  # IQ samples cross-correlated per step
@@ -492,6 +506,7 @@ def main():
                          "pair_kernel_ms_per_step": pair_ms / n_meas,
                          "whole_path_frac": alg_bytes_per_step_gpu / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "host_path_ms_per_step": host_ms,
+            "single_group": single,
             "cpu_baseline": cpu,
             "parity": parity,
         }
