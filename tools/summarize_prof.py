@@ -24,6 +24,10 @@ def main():
     out = os.path.join(root, "profiles")
     os.makedirs(out, exist_ok=True)
     ours = ("k_win", "k_fwd", "k_pair", "g_cols", "g_rows", "g_final", "g_fwd_small", "g_pair_small", "k_caf")
+    cfg = sys.argv[3] if len(sys.argv) > 3 else "cfg3"
+    # cfg3: the per-launch figures are the fused kernel's; bench.py's single-group probe (one window through k_fwd +
+    # k_pair_res, 220 tiny launches) stays in the stats table but out of the full-size selection
+    sel = ("k_win",) if cfg == "cfg3" else ours
     st = glob.glob(os.path.join(src, "stats", "*kernel_stats.csv"))
     if st:
         rows = list(csv.reader(open(st[0])))
@@ -44,7 +48,7 @@ def main():
 
     tr = glob.glob(os.path.join(src, "stats", "*kernel_trace.csv"))
     if tr:
-        rows = full_size([r for r in csv.DictReader(open(tr[0])) if any(k in r["Kernel_Name"] for k in ours)], "Grid_Size_X")
+        rows = full_size([r for r in csv.DictReader(open(tr[0])) if any(k in r["Kernel_Name"] for k in sel)], "Grid_Size_X")
         if rows:
             d = sorted(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows)
             with open(os.path.join(out, f"{tag}_kernel_stats.csv"), "a", newline="") as f:
@@ -52,7 +56,7 @@ def main():
                                         f"median_ns={d[len(d) // 2]} min_ns={d[0]} max_ns={d[-1]}"])
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for p in glob.glob(os.path.join(src, "pmc_*", "*counter_collection.csv")):
-        rows = [r for r in csv.DictReader(open(p)) if any(k in r["Kernel_Name"] for k in ours)]
+        rows = [r for r in csv.DictReader(open(p)) if any(k in r["Kernel_Name"] for k in sel)]
         by_disp = collections.defaultdict(list)
         for r in rows:
             by_disp[r["Dispatch_Id"]].append(r)
@@ -64,7 +68,6 @@ def main():
     pmc = {k: {c: sum(v) / len(v) for c, v in d.items()} | {"launches_sampled": len(next(iter(d.values())))}
            for k, d in agg.items()}
     json.dump(pmc, open(os.path.join(out, f"{tag}_pmc.json"), "w"), indent=1, sort_keys=True)
-    cfg = sys.argv[3] if len(sys.argv) > 3 else "cfg3"
     if cfg != "cfg3":
         # multi-kernel shapes: HBM bytes of ALL our kernels per engine call (= bench.py's step): counter totals over
         # every dispatch of the FETCH_SIZE / WRITE_SIZE passes divided by the engine calls bench.py reports
