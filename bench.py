@@ -2,16 +2,20 @@
 """bench.py -- BASELINE.json's metric: IQ samples cross-correlated per second + fraction of the HBM
 roofline, on synthetic IQ already resident in HBM.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg3|cfg2|cfg4|cfg5|cfg1]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg3|cfg2|cfg4|cfg5|cfg1] [--scaling weak|strong]
 
 Default workload = BASELINE configs[2] ("cfg3", the configuration the metric is quoted on): 8 buoys
 (28 pairs), 10 MS/s, 4096-sample windows, 4096 windows batched per GPU.  The other BASELINE shapes
 are selectable (they are parity-test cases; each prints the same kind of line for its own shape).
 
 A step = one pass of the hot path (IQ windows -> per-pair lags) over one batch on every rank.
-Windows shard across ranks with no data-path collective (weak scaling: every rank owns a full batch);
-rank 0 gathers the per-pair lag scalars once after the timed region.  One JSON line is printed by
-rank 0.
+Windows shard across ranks with no data-path collective -- `--scaling weak` (default): every rank owns a full
+batch; `--scaling strong`: the config's windows are block-sharded over the ranks (radio_mapper_amd.shard.window_shard,
+as BASELINE.json words cfg3/cfg4/cfg5) -- and rank 0 gathers the per-pair lag scalars once after the timed region.
+One JSON line is printed by rank 0.  At N = 1 the default run also times the other four BASELINE shapes in the same
+process (`other_configs`, a bounded number of steps each; `--no-other-configs` skips them) and reports the headline
+shape without the untimed pre-warm (`ms_per_step_cold`), its ingest rate and real-time factor, and the host-pointer
+path for complex64 and raw uint8 input.
 
 Multi-GPU: `python bench.py --gpus N` with WORLD_SIZE unset starts its own N ranks
 (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`) as a CHILD process
@@ -199,21 +203,190 @@ def cpu_baseline(get_windows, W, B, N, budget_s, doppler=None):
                       f"on 1 core: {lit_rate:.3e} samples/s over {w_lit} window(s) ({t_lit:.2f} s)", **info}
 
 
+def source_digest():
+    """sha256 over the kernel sources the library is built from (the same list __graft_entry__.build() watches): ties a
+    recorded profiles/traffic_*.json to the code it was measured on (tools/summarize_prof.py writes it, bench.py refuses a
+    figure whose digest is not the current one)."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "radio-mapper_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(csrc, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def recorded_traffic(config):
+    """(hbm bytes per launch, source text) from profiles/traffic_*.json -- only when that file was taken on the current
+    sources; a stale file yields (None, why)."""
+    tj = os.path.join(ROOT, "profiles", "traffic_latest.json" if config == "cfg3" else f"traffic_{config}.json")
+    if not os.path.exists(tj):
+        return None, None
+    try:
+        tjd = json.load(open(tj))
+    except Exception:
+        return None, None
+    now = source_digest()
+    if tjd.get("source_digest") != now:
+        return None, (f"profiles/{os.path.basename(tj)} (tag {tjd.get('tag')}) was recorded on other sources "
+                      f"(digest {tjd.get('source_digest')} != {now}): not reported; re-run tools/profile.sh")
+    return tjd.get("hbm_bytes_per_launch"), (
+        f"profiles/{os.path.basename(tj)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tag {tjd.get('tag')}, source "
+        f"digest {now}; recorded by tools/profile.sh, not measured in this run)")
+
+
+class Shape:
+    """One BASELINE shape on one device: synthetic windows resident in HBM, an engine, a step."""
+
+    def __init__(self, torch, xcorr, name, dev, dev_index, windows, buoys=None, seed_offset=0):
+        import numpy as np
+        cfg = dict(CONFIGS[name])
+        self.torch, self.name, self.cfg, self.dev = torch, name, cfg, dev
+        self.B = buoys or cfg["B"]
+        self.N, self.fs, self.C = cfg["N"], cfg["fs"], cfg["C"]
+        self.W = windows                                # (window, channel) units on this device
+        self.P = self.B * (self.B - 1) // 2
+        self.caf = "doppler_hz" in cfg
+        self.grid = None
+        buoy_dop = None
+        if self.caf:
+            nb = int(round(cfg["doppler_hz"] / cfg["doppler_step_hz"]))
+            self.grid = np.arange(-nb, nb + 1) * (cfg["doppler_step_hz"] / self.fs)       # cycles/sample, 21 bins
+            rng = np.random.default_rng(cfg["seed"])
+            buoy_dop = rng.integers(-8, 9, size=self.B) * (cfg["doppler_step_hz"] / self.fs) * 0.5   # true offsets within +-200 Hz
+        self.D = len(self.grid) if self.caf else 1
+        W, B, N, P = self.W, self.B, self.N, self.P
+        self.x, self.delays = synth_on_device(torch, dev, W, B, N, self.fs, seed=cfg["seed"] + seed_offset, doppler_cps=buoy_dop)
+        self.lag = torch.zeros((W, P), dtype=torch.int32, device=dev)
+        self.frac = torch.zeros((W, P), dtype=torch.float32, device=dev)
+        self.peak = torch.zeros((W, P), dtype=torch.float32, device=dev)
+        self.dop = torch.zeros((W, P), dtype=torch.int32, device=dev) if self.caf else None
+        self.eng = xcorr.XcorrEngine(B, N, max(W, 1), device=dev_index)
+        self.stream = torch.cuda.current_stream()
+        self.eng.set_stream(self.stream.cuda_stream)
+        self.calls = 0        # full-size engine calls (tools/summarize_prof.py divides counter totals by it)
+
+    def step(self):
+        self.calls += 1
+        if self.caf:
+            self.eng.caf_device(self.x.data_ptr(), self.W, self.grid, self.dop.data_ptr(), self.lag.data_ptr(),
+                                self.frac.data_ptr(), self.peak.data_ptr())
+        else:
+            self.eng.correlate_device(self.x.data_ptr(), self.W, self.lag.data_ptr(), self.frac.data_ptr(), self.peak.data_ptr())
+
+    def host_windows(self, a, b):
+        import numpy as np
+        return self.x[a:b].cpu().numpy().view(np.complex64).reshape(b - a, self.B, self.N)
+
+    def alg_bytes_per_step(self):
+        # algorithmic bytes (SURVEY.md section 8d): 16 N + 12 per pair-window; CAF: 16 N per pair-window-bin + 16 per pair-window
+        return self.W * self.P * ((16 * self.N) * self.D + (16 if self.caf else 12))
+
+    def parity(self, cpu_thr, light=False):
+        """the timed outputs (lag / frac / peak on the device) against the oracle on a bounded subset + ground truth"""
+        import numpy as np
+        from oracle import xcorr_ref as orc
+        li, lf = self.lag.cpu().numpy(), self.frac.cpu().numpy()
+        B, P, N, W = self.B, self.P, self.N, self.W
+        pl = orc.pair_list(B)
+        true_lag = self.delays[:, pl[:, 1]] - self.delays[:, pl[:, 0]]
+        truth_ok = float(np.mean(np.abs(li + lf - true_lag) < 1.0))
+        if self.caf:
+            # oracle on a bounded subset: window 0, the first pairs, the whole Doppler grid (32 pairs = 672 calls of the
+            # reference primitive at cfg5, about 30 s on the box's host cores; 4 pairs in the short form)
+            npr = min(4 if light else 32, P)
+            rd, ri, rf, rp = orc.caf_batch(self.host_windows(0, 1), self.grid, pl[:npr])
+            dgot = self.dop.cpu().numpy()
+            ref, got = ri + rf, li[:1, :npr] + lf[:1, :npr].astype(np.float64)
+            return {"windows": 1, "pairs": npr, "doppler_bins": self.D,
+                    "doppler_idx_mismatches": int(np.sum(dgot[:1, :npr] != rd)),
+                    "lag_int_mismatches": int(np.sum(li[:1, :npr] != ri)),
+                    "max_lag_err_rel": float(np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1.0))),
+                    "lags_within_1_sample_of_truth": truth_ok}
+        nchk = min(256 if N <= 4096 else (2 if light and N > 262144 else 8), W)   # SURVEY.md 8d: >= 256 windows at cfg3; 8 of the long ones
+        ri, rf, rp = orc.xcorr_batch_fast(self.host_windows(0, nchk), workers=cpu_thr)
+        ref = ri + rf
+        got = li[:nchk] + lf[:nchk].astype(np.float64)
+        return {"windows": nchk, "pair_windows": int(nchk * P),
+                "lag_int_mismatches": int(np.sum(li[:nchk] != ri)),
+                "max_lag_err_rel": float(np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1.0))),
+                "lags_within_1_sample_of_truth": truth_ok}
+
+    def close(self):
+        self.eng.close()
+        self.x = self.lag = self.frac = self.peak = self.dop = None
+        self.torch.cuda.empty_cache()
+
+
+def timed_steps(torch, sh, steps, sync_all):
+    """EXACTLY `steps` steps bracketed by barrier + synchronize on both sides -> (wall seconds, HIP-event ms on the launch stream)"""
+    sync_all()
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(sh.stream)
+    for _ in range(steps):
+        sh.step()
+    ev1.record(sh.stream)
+    sync_all()
+    return time.perf_counter() - t0, ev0.elapsed_time(ev1)
+
+
+def other_config(torch, xcorr, name, dev, dev_index, sync_all, cpu_thr):
+    """One of the other BASELINE shapes in the same process (N = 1): a bounded number of steps after the shape's own
+    warm-up, the same bracket, parity of the timed outputs on a short subset.  Returns the dict for `other_configs`."""
+    cfg = CONFIGS[name]
+    steps, warm = OTHER_STEPS[name]
+    t_all = time.perf_counter()
+    sh = Shape(torch, xcorr, name, dev, dev_index, cfg["W"] * cfg["C"])
+    for _ in range(warm):
+        sh.step()
+    elapsed, region_ms = timed_steps(torch, sh, steps, sync_all)
+    ms = elapsed * 1e3 / steps
+    alg = sh.alg_bytes_per_step()
+    out = {"workload": cfg["what"], "steps": steps, "warmup": warm, "ms_per_step": ms,
+           "value": sh.W * sh.P * sh.N * sh.D / (ms * 1e-3), "unit": "samples/s",
+           "alg_bytes_per_step": alg,
+           "roofline_frac": alg / (region_ms / steps * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "whole_path_frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "ingest_samples_per_s": sh.W * sh.B * sh.N / (ms * 1e-3),
+           "realtime_factor": sh.W * sh.B * sh.N / (ms * 1e-3) / (sh.B * sh.fs),
+           "parity": sh.parity(cpu_thr, light=True)}
+    tr, _src = recorded_traffic(name)
+    out["traffic"] = tr
+    sh.close()
+    out["wall_s"] = time.perf_counter() - t_all
+    return out
+
+
+OTHER_STEPS = {"cfg1": (50, 10), "cfg2": (20, 5), "cfg4": (20, 5), "cfg5": (3, 1)}   # (timed steps, warm-up) per other shape
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
-    ap.add_argument("--windows", type=int, default=None, help="windows per GPU (default: the config's)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank owns a full batch; strong: the config's windows are block-sharded over the ranks")
+    ap.add_argument("--windows", type=int, default=None, help="windows per GPU (weak) / in total (strong); default: the config's")
     ap.add_argument("--buoys", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the other four BASELINE shapes (profiling runs)")
+    ap.add_argument("--no-single-group", action="store_true", help="skip the one-window latency probe (profiling runs)")
+    ap.add_argument("--no-host-path", action="store_true", help="skip the host-pointer legs (profiling runs)")
+    ap.add_argument("--profile", action="store_true",
+                    help="the timed path and its parity only: --no-other-configs --no-single-group --no-host-path --no-cpu-baseline")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU work for cpu_baseline")
     ap.add_argument("--launch-check", action="store_true",
                     help="rendezvous + shard + gather only (no compute, no metric): tests the N-rank launcher")
     args = ap.parse_args()
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
+    if args.profile:
+        args.no_other_configs = args.no_single_group = args.no_host_path = args.no_cpu_baseline = True
 
     env_world = os.environ.get("WORLD_SIZE")
     if args.gpus > 1 and env_world is None:
@@ -286,46 +459,27 @@ def main():
     torch.cuda.set_device(dev)
 
     cfg = dict(CONFIGS[args.config])
-    B = args.buoys or cfg["B"]
-    N, fs, C = cfg["N"], cfg["fs"], cfg["C"]
-    W = (args.windows or cfg["W"]) * C            # (window, channel) units per GPU: channels are a batch axis
+    C = cfg["C"]
     steps, warm = DEFAULT_STEPS[args.config]
     steps = args.steps if args.steps is not None else steps
     warm = args.warmup if args.warmup is not None else warm
-    W_total = W * n_gpus
-    w_start, W_rank = window_shard(W_total, rank, n_gpus)
-    assert W_rank == W
-    P = B * (B - 1) // 2
-    caf = "doppler_hz" in cfg
-    grid = None
-    buoy_dop = None
-    if caf:
-        nb = int(round(cfg["doppler_hz"] / cfg["doppler_step_hz"]))
-        grid = np.arange(-nb, nb + 1) * (cfg["doppler_step_hz"] / fs)          # cycles/sample, 21 bins
-        rng = np.random.default_rng(cfg["seed"])
-        buoy_dop = rng.integers(-8, 9, size=B) * (cfg["doppler_step_hz"] / fs) * 0.5   # true offsets within +-200 Hz
-    D = len(grid) if caf else 1
-    # every rank generates its own block of the job's windows (seed per config, offset by rank)
-    x, delays = synth_on_device(torch, dev, W, B, N, fs, seed=cfg["seed"] + 7919 * rank, doppler_cps=buoy_dop)
-    lag = torch.zeros((W, P), dtype=torch.int32, device=dev)
-    frac = torch.zeros((W, P), dtype=torch.float32, device=dev)
-    peak = torch.zeros((W, P), dtype=torch.float32, device=dev)
-    dop = torch.zeros((W, P), dtype=torch.int32, device=dev) if caf else None
-
-    eng = xcorr.XcorrEngine(B, N, W, device=dev_index)
-    stream = torch.cuda.current_stream()
-    eng.set_stream(stream.cuda_stream)
-    eng.set_option("timing", 1)   # HIP events around every launch, on the launch stream
-
-    calls = [0]      # full-size engine calls made by this process (tools/summarize_prof.py divides counter totals by it)
-    if caf:
-        def step():
-            calls[0] += 1
-            eng.caf_device(x.data_ptr(), W, grid, dop.data_ptr(), lag.data_ptr(), frac.data_ptr(), peak.data_ptr())
+    if args.scaling == "strong":
+        # the job is the config's batch as BASELINE.json states it (cfg3: 4096 windows; cfg4: 4096 windows x 10 channels;
+        # cfg5: 64 windows), block-sharded over the ranks; at N = 1 one GPU owns all of it
+        job = {"cfg4": 4096, "cfg5": 64}.get(args.config, cfg["W"])
+        W_total = (args.windows or job) * C
+        w_start, W = window_shard(W_total, rank, n_gpus)
     else:
-        def step():
-            calls[0] += 1
-            eng.correlate_device(x.data_ptr(), W, lag.data_ptr(), frac.data_ptr(), peak.data_ptr())
+        W = (args.windows or cfg["W"]) * C        # (window, channel) units per GPU: channels are a batch axis
+        W_total = W * n_gpus
+        w_start, W_rank = window_shard(W_total, rank, n_gpus)
+        assert W_rank == W
+    # every rank generates its own block of the job's windows (seed per config, offset by rank)
+    sh = Shape(torch, xcorr, args.config, dev, dev_index, W, buoys=args.buoys, seed_offset=7919 * rank)
+    B, N, P, D, fs, caf = sh.B, sh.N, sh.P, sh.D, sh.fs, sh.caf
+    eng, x, lag, frac, peak = sh.eng, sh.x, sh.lag, sh.frac, sh.peak
+    eng.set_option("timing", 1)   # HIP events around every launch, on the launch stream
+    step = sh.step
 
     def sync_all():
         torch.cuda.synchronize()
@@ -333,30 +487,31 @@ def main():
             barrier()
             torch.cuda.synchronize()
 
-    # untimed pre-warm beyond the W warm-up steps: the device needs some hundred milliseconds of load to
-    # settle on its sustained clock (measured: 20 timed steps right after 5 warm-up steps run 8 % slower
-    # per step than 3000); reported as "prewarm_steps" in the JSON line
-    prewarm = 0
-    if args.config == "cfg3":
-        prewarm = max(0, int(os.environ.get("RMX_BENCH_PREWARM", "300")) - warm)
-    for _ in range(prewarm):
-        step()
+    def max_over_ranks(v):
+        if world == 1:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     for _ in range(warm):
         step()
-    sync_all()
+    # (a) the driver's own contract and nothing else: W warm-up steps, then exactly K timed steps.  On a device that has
+    # just been idle this measures the clock ramp as well: reported as ms_per_step_cold.
+    cold_elapsed, _cold_region = timed_steps(torch, sh, steps, sync_all)
+    ms_per_step_cold = max_over_ranks(cold_elapsed) * 1e3 / steps
+    # (b) untimed pre-warm, then the same K steps again: the device needs some hundred milliseconds of load to settle
+    # on its sustained clock (the first timed steps after a short warm-up run 3-8 % slower per step than 3000 do);
+    # "prewarm_steps" counts everything that ran before the headline region beyond the W warm-up steps
+    prewarm = 0
+    if args.config == "cfg3":
+        prewarm = max(0, int(os.environ.get("RMX_BENCH_PREWARM", "300")) - warm - steps)
+    for _ in range(prewarm):
+        step()
     # HIP events on the launch stream (the ctx uses torch's current stream) around the timed region:
     # the sustained, back-to-back launch duration (isolated launches run at a higher clock)
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    for _ in range(steps):
-        step()
-        # (rmx_last_timing would synchronise; it is read once per step only after the loop below)
-    ev1.record(stream)
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    region_ms = ev0.elapsed_time(ev1)
+    elapsed, region_ms = timed_steps(torch, sh, steps, sync_all)
+    prewarm += steps            # the cold region ran before the headline region too
     # kernel durations from the HIP events bracketing every launch on the launch stream: the last
     # step of the timed region, then the same step repeated with a read-back after each
     fwd_ms = pair_ms = 0.0
@@ -368,30 +523,37 @@ def main():
         tm = eng.last_timing()
         fwd_ms += tm["fwd_ms"]; fwd_n += tm["fwd_launches"]
         pair_ms += tm["pair_ms"]; pair_n += tm["pair_launches"]
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(elapsed)
     ms_per_step = elapsed * 1e3 / steps
     seen = ranks_seen()
 
-    # PCIe-inclusive rate of the same step through the host-pointer entry of the C ABI (reported in
-    # DESIGN.md, never `value`): pageable numpy in, numpy out
-    host_ms = None
-    if rank == 0 and n_gpus == 1 and args.config == "cfg3":
+    # PCIe-inclusive rate of the same step through the host-pointer entry of the C ABI (reported, never `value`):
+    # pageable numpy in, numpy out -- complex64 (8 B/sample over the link) and the reference's wire format, raw uint8
+    # I/Q (2 B/sample; the synthetic windows sit on the rtl_sdr grid, so raw = x + 127.5 exactly and the lags must agree)
+    host_ms = host_u8_ms = None
+    host_u8_same = None
+    if rank == 0 and n_gpus == 1 and args.config == "cfg3" and not args.no_host_path:
         xh = x.cpu().numpy().view(np.complex64).reshape(W, B, N)
         eng.correlate(xh[:64])
         th = time.perf_counter()
-        eng.correlate(xh)
-        calls[0] += 1
+        got_c = eng.correlate(xh)
+        sh.calls += 1
         host_ms = (time.perf_counter() - th) * 1e3
         del xh
+        raw = (x + 127.5).to(torch.uint8).cpu().numpy().reshape(W, B, 2 * N)
+        eng.correlate(raw[:64])
+        th = time.perf_counter()
+        got_u = eng.correlate(raw)
+        sh.calls += 1
+        host_u8_ms = (time.perf_counter() - th) * 1e3
+        host_u8_same = bool(all(np.array_equal(a, b) for a, b in zip(got_c, got_u)))
+        del raw, got_c, got_u
         step()                    # leave the device-pointer results of the timed path in lag/frac/peak
         torch.cuda.synchronize()
 
     # host-side gather of the lag scalars (the only exchange of the multi-GPU path)
     li, lf, pk = lag.cpu().numpy(), frac.cpu().numpy(), peak.cpu().numpy()
-    if world > 1 and backend == "nccl":
+    if world > 1 and backend == "nccl" and args.scaling == "weak":
         # every rank holds the same number of windows: plain all_gather of the three result tensors
         # (12 bytes per pair-window; outside the timed region)
         outs = []
@@ -405,44 +567,17 @@ def main():
     if rank == 0:
         assert gathered[0].shape == (W_total, P)
 
-    def host_windows(a, b):
-        return x[a:b].cpu().numpy().view(np.complex64).reshape(b - a, B, N)
-
     # parity in the same run (rank 0) + cpu baseline
     parity = None
     cpu = None
+    single = None
     if rank == 0:
-        from oracle import xcorr_ref as orc
-        true_lag = delays[:, orc.pair_list(B)[:, 1]] - delays[:, orc.pair_list(B)[:, 0]]
-        truth_ok = float(np.mean(np.abs(li + lf - true_lag) < 1.0))
-        if caf:
-            # oracle on a bounded subset: window 0, the first 32 pairs (all pairs of buoy 0 and (1, 2)), the whole
-            # Doppler grid -- 672 calls of the reference primitive at cfg5 (about 30 s on the box's host cores)
-            npr = min(32, P)
-            prs = orc.pair_list(B)[:npr]
-            rd, ri, rf, rp = orc.caf_batch(host_windows(0, 1), grid, prs)
-            dgot = dop.cpu().numpy()
-            ref, got = ri + rf, li[:1, :npr] + lf[:1, :npr].astype(np.float64)
-            parity = {"windows": 1, "pairs": npr, "doppler_bins": D,
-                      "doppler_idx_mismatches": int(np.sum(dgot[:1, :npr] != rd)),
-                      "lag_int_mismatches": int(np.sum(li[:1, :npr] != ri)),
-                      "max_lag_err_rel": float(np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1.0))),
-                      "lags_within_1_sample_of_truth": truth_ok}
-        else:
-            nchk = min(256 if N <= 4096 else 8, W)           # >= 256 windows at cfg3; 8 of the long ones
-            ri, rf, rp = orc.xcorr_batch_fast(host_windows(0, nchk), workers=cpu_threads())
-            ref = ri + rf
-            got = li[:nchk] + lf[:nchk].astype(np.float64)
-            parity = {"windows": nchk, "pair_windows": int(nchk * P),
-                      "lag_int_mismatches": int(np.sum(li[:nchk] != ri)),
-                      "max_lag_err_rel": float(np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1.0))),
-                      "lags_within_1_sample_of_truth": truth_ok}
+        parity = sh.parity(cpu_threads())
         if n_gpus == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(host_windows, W, B, N, args.cpu_budget, doppler=grid)
+            cpu = cpu_baseline(sh.host_windows, W, B, N, args.cpu_budget, doppler=sh.grid)
         # latency of ONE window of the same shape (the reference's call pattern: one frequency group per call), device
         # pointers, outside the timed region; extra information, not part of the metric
-        single = None
-        if not caf:
+        if not caf and not args.no_single_group:
             eng.set_option("timing", 0)
             one = lambda: eng.correlate_device(x.data_ptr(), 1, lag.data_ptr(), frac.data_ptr(), peak.data_ptr())
             for _ in range(20):
@@ -453,13 +588,25 @@ def main():
                 one()
             torch.cuda.synchronize()
             single = {"windows": 1, "us_per_call": (time.perf_counter() - t0) / 200 * 1e6}
+    calls_headline = sh.calls
+    fused = (N == 4096 and not caf)
+    alg_bytes_per_step_gpu = sh.alg_bytes_per_step()
+    headline_workload = cfg["what"]
+    sh.close()
+
+    # the other BASELINE shapes, same process, N = 1 only (they are parity-test cases, not the metric: bounded steps)
+    others = None
+    if rank == 0 and n_gpus == 1 and args.config == "cfg3" and not args.no_other_configs:
+        others = {}
+        for name in ("cfg1", "cfg2", "cfg4", "cfg5"):
+            try:
+                others[name] = other_config(torch, xcorr, name, dev, dev_index, sync_all, cpu_threads())
+            except Exception as e:      # a shape that fails must not take the headline line with it
+                others[name] = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         units_per_step = W_total * P * N * D                  # IQ samples cross-correlated per step
         value = units_per_step / (ms_per_step * 1e-3)
-        # algorithmic bytes: 16 N + 12 per pair-window; CAF: 16 N per pair-window-bin
-        alg_bytes_per_step_gpu = W * P * ((16 * N) * D + (16 if caf else 12))
-        fused = (N == 4096 and not caf)
         if fused:
             launches_per_step = max(pair_n / n_meas, 1.0)
             kernel = "k_win (fused forward + pair kernel), one launch per step"
@@ -467,10 +614,10 @@ def main():
             isolated_launch_ms = pair_ms / max(pair_n, 1)
         else:
             # multi-kernel paths: the figure is for the whole kernel sequence of one step (HIP events on the
-            # launch stream around the timed region); per-kernel durations are in profiles/r02_<cfg>_*
+            # launch stream around the timed region); per-kernel durations are in profiles/r04_<cfg>_*
             launches_per_step = 1.0
             kernel = ("rmx_caf_batch kernel sequence (un-rotated spectra once; per Doppler bin: de-rotated forward "
-                      "g_cols_fwd + g_rows, g_rows(product, inverse), g_cols_inv, g_final, k_caf_select)" if caf else
+                      "g_cols_fwd + g_rows, g_rows_anchor(product, inverse), g_cols_inv, g_final, k_caf_select)" if caf else
                       ("four-step sequence g_cols_fwd + g_rows_fused (forward rows, products, inverse rows) + g_cols_inv "
                        "+ g_final" if B <= 4 and W >= 4 else
                        "four-step sequence g_cols_fwd + g_rows + g_rows(product, inverse) + g_cols_inv + g_final"))
@@ -478,23 +625,16 @@ def main():
             isolated_launch_ms = None
         alg_bytes_per_launch = alg_bytes_per_step_gpu / launches_per_step
         achieved = alg_bytes_per_launch / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
-        traffic = traffic_src = None
-        tj = os.path.join(ROOT, "profiles", "traffic_latest.json" if args.config == "cfg3" else f"traffic_{args.config}.json")
-        if os.path.exists(tj):
-            try:
-                tjd = json.load(open(tj))
-                traffic = tjd.get("hbm_bytes_per_launch")
-                traffic_src = f"profiles/{os.path.basename(tj)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tag " \
-                              f"{tjd.get('tag')}; recorded by tools/profile.sh, not measured in this run)"
-            except Exception:
-                traffic = None
-        unit = "samples/s"
+        traffic, traffic_src = recorded_traffic(args.config)
+        ingest = W_total * B * N / (ms_per_step * 1e-3)       # input samples taken in per second, all ranks
         line = {
             "metric": "IQ samples cross-correlated per second" + (" (pair-window-Doppler-bin samples)" if caf else ""),
-            "value": value, "unit": unit, "n_gpus": n_gpus, "ranks_seen": seen, "steps": steps,
-            "warmup": warm, "prewarm_steps": prewarm, "engine_calls": calls[0], "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": cfg["what"], "name": args.config,
+            "value": value, "unit": "samples/s", "n_gpus": n_gpus, "ranks_seen": seen, "steps": steps,
+            "warmup": warm, "prewarm_steps": prewarm, "engine_calls": calls_headline, "ms_per_step": ms_per_step,
+            "ms_per_step_cold": ms_per_step_cold,
+            "higher_is_better": True,
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": headline_workload, "name": args.config,
                        "n_buoys": B, "n_pairs": P, "n_samples": N, "windows_per_gpu": W, "channels": C,
                        "doppler_bins": D if caf else None,
                        "windows_total": W_total, "parallelism": f"windows sharded x{n_gpus}, no collective"},
@@ -504,14 +644,21 @@ def main():
                          "launch_ms": launch_ms, "isolated_launch_ms": isolated_launch_ms,
                          "fwd_kernel_ms_per_step": fwd_ms / n_meas,
                          "pair_kernel_ms_per_step": pair_ms / n_meas,
-                         "whole_path_frac": alg_bytes_per_step_gpu / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                         "whole_path_frac": alg_bytes_per_step_gpu / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "whole_path_frac_cold": alg_bytes_per_step_gpu / (ms_per_step_cold * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "fp32_valu_and_lds": "DESIGN.md section 6 (profiles/*_pmc.json): the fused kernel is bound by fp32 VALU "
+                                              "issue (70 % of the launch), not by HBM; SQ counters per launch are recorded there"},
+            "ingest_samples_per_s": ingest,
+            "realtime_factor": ingest / (B * fs),               # seconds of every buoy's signal processed per second
             "host_path_ms_per_step": host_ms,
+            "host_path_u8_ms_per_step": host_u8_ms,
+            "host_path_u8_identical": host_u8_same,
             "single_group": single,
+            "other_configs": others,
             "cpu_baseline": cpu,
             "parity": parity,
         }
         print(json.dumps(line), flush=True)
-    eng.close()
     if world > 1:
         barrier()
         dist.destroy_process_group()

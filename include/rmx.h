@@ -14,6 +14,10 @@
  *         c   = correlate(x[w][j], x[w][i], mode='full', method='fft')   (complex64, 2N-1 lags)
  *         m   = |c|                                                     (float32)
  *         k   = argmax m   (ties -> lowest k)        lag_int  = k - (N-1)
+ *               (Parity statement: lag_int is BIT-EXACT against scipy's float32 path wherever that path's own two
+ *               largest magnitudes differ by more than 1e-5 relative -- every committed fixture, every BASELINE shape --
+ *               and the lowest index on exact ties.  Where two candidates are closer than that, two correct float32
+ *               FFTs may order them differently; the tests accept only the oracle's own second candidate there.)
  *               (The kernels search the maximum of |c|^2 and take the square root of the three taps only.  sqrt is
  *               monotonic, so the two orders agree except in one class of inputs: two lags whose |c|^2 differ in the
  *               last bit but whose float32 |c| round to the SAME value.  numpy then sees a tie and takes the lower
@@ -26,7 +30,9 @@
  *               wherever that formula is well conditioned -- 8.7 M random pair-windows, N = 16 ... 2^18, worst 7e-6 --
  *               and to the formula's own conditioning where it is not: two pair-windows of those, e.g. a flat peak on a
  *               32-sample window at 0 dB (a - 2b + c = 4e-3 b), where one float32 ulp on each tap moves d by 2.3e-5,
- *               differed by 3.3e-5: tools/soak_parity.py.)
+ *               differed by 3.3e-5.  The rule -- within 1e-5, or within four such
+ *               one-ulp bounds, nothing else -- is pinned in tests/test_gpu_parity.py::test_flat_peak_rule_on_short_noisy_windows
+ *               and used by tests/soak_parity.py.)
  *         peak = m[k]
  *     lag = lag_int + lag_frac samples = delay(buoy j) - delay(buoy i)   (sign of
  *     TDoAMeasurement.time_difference_ns: buoy2 - buoy1, tdoa_processor.py:51).
@@ -96,8 +102,8 @@ int rmx_set_stream(rmx_ctx* ctx, void* hip_stream);
  * about 0.25 ... 0.5 windows per CU, depending on the buoy count -- run through those per-transform kernels, which spread
  * one window's spectra and pairs over the CUs: 13 us instead of 92 us for a single window of 8 buoys; 0: always the
  * fused kernel), "stag" (0..5: which waves of the fused N = 4096 kernel run the two halves
- * between barriers in the opposite order; default 1), "win8" / "pk" (the two other builds of that kernel,
- * present only in a -DRMX_EXPERIMENTS build, RMX_E_UNSUPPORTED otherwise), "dbg"
+ * between barriers in the opposite order; default 1), "win8" / "pk" (two other builds of that kernel,
+ * tools/experiments/: present only in a -DRMX_EXPERIMENTS build, RMX_E_UNSUPPORTED otherwise), "dbg"
  * (ablation masks of the -DRMX_ABLATE timing build; every other build rejects the key with
  * RMX_E_UNSUPPORTED and compiles the masks out of all kernels).
  * Returns RMX_E_INVAL for an unknown key. */

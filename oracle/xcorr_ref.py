@@ -239,3 +239,23 @@ def decode_u8_iq(raw: np.ndarray) -> np.ndarray:
     iq_stream_client.py:149-157: astype(float32) - 127.5, I + 1j*Q, no scaling."""
     f = np.asarray(raw, dtype=np.uint8).astype(np.float32) - np.float32(127.5)
     return (f[..., 0::2] + 1j * f[..., 1::2]).astype(np.complex64)
+
+
+def parabola_ulp_bound(x_i, x_j):
+    """How far one float32 ulp on each of the three taps moves the interpolated lag, relative to max(|lag|, 1): the part
+    of a lag difference that two correct float32 transforms cannot avoid (a flat peak: a - 2b + c small against b)."""
+    m = np.abs(xcorr_full_scipy(x_i, x_j)).astype(np.float32)
+    n = x_i.shape[-1]
+    k = int(np.argmax(m))
+    if k == 0 or k == 2 * n - 2:
+        return 0.0
+    a, b, c = (float(v) for v in m[k - 1:k + 2])
+    den = a - 2.0 * b + c
+    if den == 0.0:
+        return 0.0
+    ulp = float(np.spacing(np.float32(b)))
+    pa = 0.5 * (1.0 / den - (a - c) / den ** 2)
+    pb = (a - c) / den ** 2
+    pc = 0.5 * (-1.0 / den - (a - c) / den ** 2)
+    lag = (k - (n - 1)) + 0.5 * (a - c) / den
+    return (abs(pa) + abs(pb) + abs(pc)) * ulp / max(abs(lag), 1.0)

@@ -397,7 +397,7 @@ __device__ __forceinline__ void loc_write4(int m0, const float2& a, const float2
           "n"(loc_pos(S0) * kLocRow), "n"(kLocPlane + loc_pos(S0) * kLocRow), "n"(loc_pos(S1) * kLocRow),
           "n"(kLocPlane + loc_pos(S1) * kLocRow), "n"(loc_pos(S2) * kLocRow), "n"(kLocPlane + loc_pos(S2) * kLocRow),
           "n"(loc_pos(S3) * kLocRow), "n"(kLocPlane + loc_pos(S3) * kLocRow)
-        : "memory");
+        : "memory", "m0");   // (M0 is written here: the compiler must not keep a value of its own in it across the statement)
 }
 __device__ __forceinline__ void loc_write16(int m0, const float2 (&v)[16]) {
     loc_write4<0, 1, 2, 3>(m0, v[0], v[1], v[2], v[3]);

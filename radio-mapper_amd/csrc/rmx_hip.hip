@@ -27,8 +27,11 @@
 #include "host_plan.hpp"
 #include "fft_r16.hpp"
 #include "kwin.hpp"
-#include "win8.hpp"    // (radix-8 register blocks shared with generic_path.hpp; its kernel k_win8 is instantiated only under
-#include "winpk.hpp"   //  -DRMX_EXPERIMENTS, like k_winp: templates that nothing references cost nothing)
+#include "fft_r8.hpp"
+#ifdef RMX_EXPERIMENTS   // k_win8 / k_winp: two other builds of the fused kernel, measured slower (tools/experiments/README.md)
+#include "../../tools/experiments/win8.hpp"
+#include "../../tools/experiments/winpk.hpp"
+#endif
 #include "generic_path.hpp"
 #include "win_eo.hpp"
 #include "detect_path.hpp"
@@ -1759,12 +1762,22 @@ int rmx_xcorr_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pa
     // The same arithmetic for the LAST round of a larger batch: W = k CUs + r windows cost the fused kernel k + 1 rounds
     // (300 windows of 8 buoys: two rounds, 184 us); when the model says the r windows are cheaper through the
     // per-transform kernels than a round of the fused one, they go there (after the k full rounds, on the same stream).
+    // The decision is taken per CHUNK of windows (a batch-wide tail larger than the last chunk ran past the
+    // chunk and past the spectrum scratch): chunk_tail(w0, wc) below is the chunk's own partial round, wc mod CUs, so it
+    // never exceeds the chunk, and the scratch of min(chunk, CUs) window slots covers it.  `tail` here only says that
+    // some chunk may take that route, and sizes the pair workgroups for the batch's last partial round.
     int tail = 0;
-    if (!small && !c->generic && c->fused && c->small_batch && c->n_buoys >= 3 && n_pairs == all_pairs && c->n_cus > 0 &&
-        n_windows > c->n_cus && n_windows % c->n_cus != 0 && (in_dev || n_windows <= kHostSubChunk)) {
+    const bool tail_ok = !small && !c->generic && c->fused && c->small_batch && c->n_buoys >= 3 && n_pairs == all_pairs &&
+                         c->n_cus > 0 && (in_dev || n_windows <= kHostSubChunk);
+    auto tail_pays = [&](int r, int* q) -> bool {
+        return split_cost4096(c, r, n_pairs, q) < 0.9 * host::fused_cost4096(c->n_cus, c->n_buoys, n_pairs, 1);
+    };
+    if (tail_ok && n_windows > c->n_cus) {
+        const long cw = c->chunk_windows;
+        const int last_wc = (int)(n_windows - ((long)(n_windows - 1) / cw) * cw);   // windows of the last chunk
+        const int r = last_wc % c->n_cus;
         int q = 7;
-        const int r = n_windows % c->n_cus;
-        if (split_cost4096(c, r, n_pairs, &q) < 0.9 * host::fused_cost4096(c->n_cus, c->n_buoys, n_pairs, 1)) {
+        if (r != 0 && tail_pays(r, &q)) {
             tail = r;
             ppb_small = q;
         }
@@ -1849,7 +1862,14 @@ int rmx_xcorr_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pa
     for (int w0 = 0; w0 < n_windows; w0 += c->chunk_windows) {
         const int wc = (n_windows - w0 < c->chunk_windows) ? n_windows - w0 : c->chunk_windows;
         if (fused_now) {
-            const int wtail = (tail && w0 + wc == n_windows) ? tail : 0;   // the batch's last partial round (see above)
+            // this chunk's partial round (see above): only behind at least one full round of this call, and only when the
+            // model says so for ITS size -- with the default chunk (a multiple of the CU count) that is the batch's last
+            // partial round; 0 <= wtail < CUs and wtail <= wc by construction
+            int wtail = 0;
+            if (tail && (w0 > 0 || wc > c->n_cus) && wc % c->n_cus != 0) {
+                int q_unused = 7;
+                if (tail_pays(wc % c->n_cus, &q_unused)) wtail = wc % c->n_cus;
+            }
             const int wf = wc - wtail;
             const int sub = pipelined ? kHostSubChunk : (wf > 0 ? wf : 1);
             for (int s0 = 0; s0 < wf; s0 += sub) {

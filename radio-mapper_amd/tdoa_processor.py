@@ -234,13 +234,27 @@ class TDoACalculator:
         if any(a is None for a in iqs):
             self.logger.error("Only some detections of the group carry IQ windows; no TDoA measurements for it")
             return False, None
-        shapes = {(a.dtype.str, a.shape) for a in iqs}
         rates = {float(d.sample_rate_hz) for d in detections}
-        if len(shapes) != 1 or len(rates) != 1:
-            self.logger.error("IQ windows of the group differ in length/dtype/sample rate; no TDoA measurements for it")
+        kinds = {(a.dtype.str, a.ndim) for a in iqs}
+        if len(kinds) != 1 or len(rates) != 1 or iqs[0].ndim != 1:
+            self.logger.error("IQ windows of the group differ in dtype/sample rate; no TDoA measurements for it")
             return False, None
-        dt, shp = next(iter(shapes))
-        return (len(iqs), dt, shp, next(iter(rates))), np.stack(iqs)
+        # Windows that differ in length, or whose length is not a power of two: the reference clips an excerpt at the
+        # end of the capture buffer (iq_stream_client.py:306-313: start = max(0, peak - 128), end = min(len, start + 256)),
+        # so a peak in the last 128 bins gives e.g. 130 samples beside the other buoys' 256.  Every window keeps its
+        # START (that is what its time tag dates), so the group is cut to the largest power of two that every window
+        # holds -- the engine's window lengths -- instead of being dropped (ADVICE r03).
+        per = 2 if iqs[0].dtype == np.uint8 else 1          # uint8: interleaved I, Q
+        nmin = min(a.shape[0] // per for a in iqs)
+        n = 1 << (max(nmin, 1).bit_length() - 1)
+        if nmin < 16:
+            self.logger.error(f"IQ windows of the group are too short to correlate ({nmin} samples); no TDoA measurements for it")
+            return False, None
+        if any(a.shape[0] != n * per for a in iqs):
+            self.logger.warning(f"IQ windows of the group hold {sorted({a.shape[0] // per for a in iqs})} samples; "
+                                f"correlating their first {n}")
+            iqs = [a[:n * per] for a in iqs]
+        return (len(iqs), iqs[0].dtype.str, iqs[0].shape, next(iter(rates))), np.stack(iqs)
 
     def _measure_groups(self, stacked: np.ndarray):
         """[G][B][N] -> lag [G][P] float64, or None after logging: the reference's seam never raises
@@ -303,7 +317,11 @@ class TDoACalculator:
         if lag is not None:
             # the same float64 arithmetic as `round(lag[q] / fs * 1e9)` per pair, done once for the group (numpy scalars make
             # the pair loop four times slower than it needs to be; np.rint and round() both round half to even)
-            lag_ns = np.rint(np.asarray(lag, np.float64) / fs * 1e9).astype(np.int64).tolist()
+            lag_s = np.asarray(lag, np.float64) / fs
+            if not np.all(np.isfinite(lag_s)):           # (a NaN would become INT64_MIN in the cast below)
+                self.logger.error("Cross-correlation returned a non-finite lag; no TDoA measurements for the group")
+                return out
+            lag_ns = np.rint(lag_s * 1e9).astype(np.int64).tolist()
         debug = self.logger.isEnabledFor(logging.DEBUG)
         for i in range(nd):
             for j in range(i + 1, nd):

@@ -101,20 +101,27 @@ def clear_default_options() -> None:
     load_library().rmx_clear_default_options()
 
 
-def apply_env_options(environ=None) -> dict:
+def apply_env_options(environ=None, strict: bool = True, report=None) -> dict:
     """For the tools/ scripts only: turns RMX_<KEY>=<int> environment variables into default options (the library
-    itself never reads the environment).  Returns what was applied."""
+    itself never reads the environment).  Returns what was applied.  A variable the library refuses (unknown key, value
+    out of range, not an integer) raises ValueError when `strict` -- an A/B run must not silently measure the default
+    path -- and is only reported otherwise; `report` (a file object, stderr in the tools) gets one line
+    with what was applied and what was refused."""
     import os as _os
     env = _os.environ if environ is None else environ
-    done = {}
-    for k, v in env.items():
+    done, refused = {}, {}
+    for k, v in sorted(env.items()):
         if not k.startswith("RMX_") or k in ("RMX_LIBRARY", "RMX_CPU_THREADS") or k.startswith("RMX_BENCH"):
             continue
         try:
             set_default_option(k[4:].lower(), int(v))
             done[k[4:].lower()] = int(v)
-        except (RmxError, ValueError):
-            pass
+        except (RmxError, ValueError) as e:
+            refused[k] = str(e)
+    if report is not None and (done or refused):
+        print(f"[rmx options] applied {done}" + (f"  REFUSED {refused}" if refused else ""), file=report, flush=True)
+    if refused and strict:
+        raise ValueError(f"environment options the library refused: {refused}")
     return done
 
 

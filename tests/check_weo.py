@@ -1,4 +1,4 @@
-"""GPU box: the N = 16384 whole-window kernel (g_win_eo15, win_eo.hpp) against the oracle and against the four-step path\non the same input (complex64, raw uint8, a custom pair list), then timings of both.   usage: python tools/check_weo.py"""
+"""GPU box: the N = 16384 whole-window kernel (g_win_eo15, win_eo.hpp) against the oracle and against the four-step path\non the same input (complex64, raw uint8, a custom pair list), then timings of both.   usage: python tests/check_weo.py"""
 import sys, time
 sys.path.insert(0, '/root/repo')
 import numpy as np

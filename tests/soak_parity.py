@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Parity soak on the GPU box: random shapes, seeds, input types and pair lists through the C ABI against the oracle.
 
-    python tools/soak_parity.py [--seconds 240] [--seed 0] > gpurun_out/soak.txt
+    python tests/soak_parity.py [--seconds 240] [--seed 0] > gpurun_out/soak.txt
 
 Every case draws (N, B, W, input type, default or custom pair list, noise level) from the ranges the kernels dispatch
 on -- the fused N = 4096 kernel and its custom-pair-list kernels, the whole-window kernels (N = 256 ... 16 384), the
@@ -23,26 +23,6 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 TOL = 1e-5
-
-
-def parabola_ulp_bound(orc, x_i, x_j):
-    """How far one float32 ulp on each of the three taps moves the interpolated lag, relative to max(|lag|, 1): the part
-    of a lag difference that two correct float32 transforms cannot avoid (a flat peak: a - 2b + c small against b)."""
-    m = np.abs(orc.xcorr_full_scipy(x_i, x_j)).astype(np.float32)
-    n = x_i.shape[-1]
-    k = int(np.argmax(m))
-    if k == 0 or k == 2 * n - 2:
-        return 0.0
-    a, b, c = (float(v) for v in m[k - 1:k + 2])
-    den = a - 2.0 * b + c
-    if den == 0.0:
-        return 0.0
-    ulp = float(np.spacing(np.float32(b)))
-    pa = 0.5 * (1.0 / den - (a - c) / den ** 2)
-    pb = (a - c) / den ** 2
-    pc = 0.5 * (-1.0 / den - (a - c) / den ** 2)
-    lag = (k - (n - 1)) + 0.5 * (a - c) / den
-    return (abs(pa) + abs(pb) + abs(pc)) * ulp / max(abs(lag), 1.0)
 
 
 def soak_detect(args, rng, t_end, xcorr):
@@ -240,7 +220,7 @@ def main():
         if lag_err > TOL:
             plist = orc.pair_list(B) if pairs is None else pairs
             for w, q in zip(*np.nonzero(rel > TOL)):
-                bound = parabola_ulp_bound(orc, iq[w, int(plist[q, 0])], iq[w, int(plist[q, 1])])
+                bound = orc.parabola_ulp_bound(iq[w, int(plist[q, 0])], iq[w, int(plist[q, 1])])
                 if rel[w, q] <= 4.0 * bound:
                     ill += 1
                 else:

@@ -91,7 +91,14 @@ def test_default_options_are_validated_and_never_come_from_the_environment(lib, 
     with pytest.raises(xcorr.RmxError):
         xcorr.set_default_option("stag", 17)
     xcorr.set_default_option("stag", 0)
-    assert xcorr.apply_env_options({"RMX_WSCR": "2", "RMX_LIBRARY": "x", "RMX_NOPE": "1", "RMX_FUSED": "zz", "HOME": "/"}) == {"wscr": 2}
+    env = {"RMX_WSCR": "2", "RMX_LIBRARY": "x", "RMX_NOPE": "1", "RMX_FUSED": "zz", "HOME": "/"}
+    assert xcorr.apply_env_options(env, strict=False) == {"wscr": 2}
+    with pytest.raises(ValueError, match="RMX_NOPE"):            # a refused knob does not pass silently
+        xcorr.apply_env_options(env)
+    import io
+    buf = io.StringIO()
+    assert xcorr.apply_env_options({"RMX_WSCR": "1", "RMX_BENCH_SAME_DEVICE": "1"}, report=buf) == {"wscr": 1}
+    assert "applied {'wscr': 1}" in buf.getvalue() and "REFUSED" not in buf.getvalue()
     xcorr.clear_default_options()
     blob = open(xcorr.library_path(), "rb").read()
     assert b"getenv" not in blob or all(k not in blob for k in (b"RMX_WSCR", b"RMX_FUSED", b"RMX_STAG", b"RMX_NCUS", b"RMX_COL_LOGT"))

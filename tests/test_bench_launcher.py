@@ -48,3 +48,24 @@ def test_parent_does_not_import_torch_before_spawning():
     assert "import torch" not in head and "import numpy" not in head
     body = src[src.index("def main()"):]
     assert body.index("launch_ranks(args.gpus") < body.index("import torch")
+
+
+def test_recorded_traffic_is_refused_when_taken_on_other_sources(tmp_path, monkeypatch):
+    """roofline.traffic comes from a file recorded by tools/profile.sh; bench.py reports it only when the file carries the
+    digest of the kernel sources as they are now."""
+    import importlib
+    import bench
+    importlib.reload(bench)
+    d = bench.source_digest()
+    assert len(d) == 16 and d == bench.source_digest()
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "source_digest", lambda: d)
+    (prof / "traffic_latest.json").write_text(json.dumps({"hbm_bytes_per_launch": 8.4e9, "tag": "rXX", "source_digest": d}))
+    (prof / "traffic_cfg2.json").write_text(json.dumps({"hbm_bytes_per_launch": 1.5e10, "tag": "old", "source_digest": "0" * 16}))
+    tr, src = bench.recorded_traffic("cfg3")
+    assert tr == 8.4e9 and "rXX" in src
+    tr, src = bench.recorded_traffic("cfg2")
+    assert tr is None and "other sources" in src
+    assert bench.recorded_traffic("cfg4") == (None, None)

@@ -494,6 +494,67 @@ def test_cfg5_full_doppler_grid(xc):
     _assert_parity(li[:, sel], lf[:, sel], pk[:, sel], ri, rf, rp)
 
 
+def test_cfg5_shape_of_one_gpu_all_eight_windows(xc):
+    """BASELINE configs[4] at the shape ONE GPU owns (64 windows sharded over 8 GPUs = 8 windows): 32 buoys (496 pairs),
+    N = 262144 at 20 MS/s, 21 hypotheses, W = 8 in one rmx_caf_batch call (the suite only ran one window).
+    Ground truth on every window -- lag within a sample for all 8 x 496 pair-windows, Doppler bin exact for the on-grid
+    offsets -- and the oracle on the same four pairs of window 0 as test_cfg5_full_doppler_grid."""
+    B, N, fs, D, W = 32, 262144, 20e6, 21, 8
+    step = 50.0 / fs
+    grid = (np.arange(D) - D // 2) * step
+    rng = np.random.default_rng(6)
+    offs = rng.integers(-5, 6, size=B) * step              # per-buoy Doppler in +-250 Hz: pairs within +-500 Hz
+    iq, delays = rm.synth.make_windows(W, B, N, fs, seed=1005, doppler_cps=offs)
+    with xc.XcorrEngine(B, N, W) as eng:
+        dop, li, lf, pk = eng.caf(iq, grid)
+    pairs = orc.pair_list(B)
+    true = delays[:, pairs[:, 1]] - delays[:, pairs[:, 0]]
+    assert li.shape == (W, 496) and np.all(np.abs(li + lf - true) < 1.0)
+    rel = np.rint((offs[pairs[:, 1]] - offs[pairs[:, 0]]) / step).astype(int) + D // 2
+    assert np.array_equal(dop, np.broadcast_to(rel, (W, 496)))
+    sel = np.array([0, 100, 300, 495])
+    rd, ri, rf, rp = orc.caf_batch(iq[:1], grid, pairs[sel])
+    assert np.array_equal(dop[:1, sel], rd)
+    _assert_parity(li[:1, sel], lf[:1, sel], pk[:1, sel], ri, rf, rp)
+
+
+def test_flat_peak_rule_on_short_noisy_windows(xc):
+    """The two documented parity exceptions, pinned where the suite sees them (include/rmx.h next to lag_int / lag_frac;
+    VERDICT r03 item 4).  Short windows at 0 - 3 dB are where they occur: >= 1e5 seeded pair-windows of N = 16, 32, 64.
+      * integer lag: bit-exact, or the oracle's own two largest magnitudes are within 1e-5 AND the GPU's lag is the
+        oracle's second candidate;
+      * fractional lag: within 1e-5 * max(|lag|, 1), or within FOUR times what one float32 ulp on each of the oracle's
+        own three taps moves the parabola's vertex (oracle.parabola_ulp_bound: a flat peak, a - 2b + c small against b);
+      * nothing else; and the exceptions stay rare (a handful per 1e5), so a broken kernel cannot hide behind them."""
+    total = n_int_excused = n_flat = 0
+    worst = 0.0
+    for N, W, snr, seed in ((16, 1300, 0.0, 41), (32, 1300, 0.0, 42), (64, 1000, 3.0, 43)):
+        B = 8
+        iq, _ = rm.synth.make_windows(W, B, N, 10e6, seed=seed, snr_db=snr)
+        ri, rf, rp = orc.xcorr_batch_fast(iq, workers=8)
+        with xc.XcorrEngine(B, N, W) as eng:
+            li, lf, pk = eng.correlate(iq)
+        plist = orc.pair_list(B)
+        total += li.size
+        bad = li != ri
+        for w, q in zip(*np.nonzero(bad)):
+            margin, _, second = orc.peak_top2(iq[w, plist[q, 0]], iq[w, plist[q, 1]])
+            assert margin <= TOL and li[w, q] == second, f"N={N} window {w} pair {q}: integer lag {li[w, q]} vs {ri[w, q]}, margin {margin:.2e}"
+            n_int_excused += 1
+        ok = ~bad
+        ref = ri + rf
+        rel = np.where(ok, np.abs(li + lf.astype(np.float64) - ref) / np.maximum(np.abs(ref), 1.0), 0.0)
+        worst = max(worst, float(rel.max()))
+        for w, q in zip(*np.nonzero(rel > TOL)):
+            bound = orc.parabola_ulp_bound(iq[w, plist[q, 0]], iq[w, plist[q, 1]])
+            assert rel[w, q] <= 4.0 * bound, f"N={N} window {w} pair {q}: lag off by {rel[w, q]:.2e}, 4 ulp bounds = {4 * bound:.2e}"
+            n_flat += 1
+        assert np.allclose(pk[ok], rp[ok], rtol=1e-5, atol=0)
+    assert total >= 100_000
+    assert n_int_excused <= 20 and n_flat <= 20, (n_int_excused, n_flat)
+    print(f"flat-peak rule: {total} pair-windows, {n_int_excused} near-tie integer lags, {n_flat} flat-peak lags, worst rel {worst:.2e}")
+
+
 def test_cfg2_full_size_properties(xc):
     """BASELINE cfg2: 3 buoys, 64 windows of 2^20 samples at 2.4 MS/s (four-step path), generated on the
     device: ground truth, closure, and the literal oracle on two of the windows."""
@@ -593,42 +654,6 @@ def test_mixed_call_patterns_on_one_engine(xc):
         assert np.array_equal(lag.cpu().numpy(), a[0]) and np.array_equal(frac.cpu().numpy(), a[1])
         hp, hc, hi = eng.solve(buoys, a[0], a[1], 10e6)
         assert np.array_equal(pos.cpu().numpy(), hp) and np.array_equal(its.cpu().numpy(), hi)
-
-
-@pytest.mark.parametrize("opt", ["win8", "pk"])
-def test_alternative_window_kernels(xc, golden_dir, opt):
-    """The two alternative builds of the fused N = 4096 kernel -- k_win8 (8 points x 1024 threads, radix-8,
-    4 waves per SIMD) and k_winp (k_win on packed fp32) -- against the reference-generated fixture, the
-    exact-tie construction and the default kernel on a few hundred windows (complex64 and raw uint8)."""
-    g = np.load(os.path.join(golden_dir, "xcorr_b8_n4096.npz"))
-    iq = orc.decode_u8_iq(g["raw_u8"])
-    W, B, N = iq.shape
-    with xc.XcorrEngine(B, N, W) as eng:
-        try:
-            eng.set_option(opt, 1)
-        except xc.RmxError as e:
-            assert e.code == -5 and "RMX_EXPERIMENTS" in str(e)     # RMX_E_UNSUPPORTED: the default build has neither kernel
-            pytest.skip("k_win8 / k_winp are compiled only with -DRMX_EXPERIMENTS")
-        li, lf, pk = eng.correlate(iq)
-        _assert_parity(li, lf, pk, g["lag_int"], g["lag_frac"], g["peak"], g["margin"])
-        li8, lf8, pk8 = eng.correlate(g["raw_u8"])
-        assert np.array_equal(li, li8) and np.array_equal(lf, lf8) and np.array_equal(pk, pk8)
-    e = np.zeros((1, 2, N), np.complex64)
-    a = 777
-    e[0, 0, 0] = 1.0; e[0, 0, N // 2] = 1.0
-    e[0, 1, a] = 1.0; e[0, 1, a + N // 2] = -1.0
-    with xc.XcorrEngine(2, N, 1) as eng:
-        eng.set_option(opt, 1)
-        li, lf, pk = eng.correlate(e)
-    assert li[0, 0] == a - N // 2 and abs(pk[0, 0] - 1.0) < 1e-5      # exact tie -> lowest 'full' index
-    for nb, nw in ((3, 5), (8, 300), (16, 3)):
-        x, _ = rm.synth.make_windows(nw, nb, N, 10e6, seed=77 + nb)
-        with xc.XcorrEngine(nb, N, nw) as eng:
-            l0, f0, p0 = eng.correlate(x)
-            eng.set_option(opt, 1)
-            l1, f1, p1 = eng.correlate(x)
-        assert np.array_equal(l0, l1)
-        assert np.allclose(l0 + f0, l1 + f1, atol=TOL) and np.allclose(p0, p1, rtol=1e-5)
 
 
 @pytest.mark.parametrize("N,B", [(16384, 2), (16384, 4), (32768, 3), (65536, 4), (131072, 2), (262144, 4), (524288, 3)])
@@ -810,29 +835,85 @@ def test_one_engine_alternates_between_small_and_large_batches(xc):
             seen[W] = got
 
 
+def _correlate_dev(eng, iq):
+    """the engine through device pointers (RMX_IN_DEVICE | RMX_OUT_DEVICE): host numpy in, three host arrays out"""
+    import torch
+    W, B, N = iq.shape
+    dev = torch.device("cuda:0")
+    x = torch.from_numpy(np.ascontiguousarray(iq).view(np.float32).reshape(W, B, N, 2)).to(dev)
+    P = B * (B - 1) // 2
+    lag = torch.zeros((W, P), dtype=torch.int32, device=dev)
+    frac = torch.zeros((W, P), dtype=torch.float32, device=dev)
+    peak = torch.zeros((W, P), dtype=torch.float32, device=dev)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    eng.correlate_device(x.data_ptr(), W, lag.data_ptr(), frac.data_ptr(), peak.data_ptr())
+    torch.cuda.synchronize()
+    return lag.cpu().numpy(), frac.cpu().numpy(), peak.cpu().numpy()
+
+
+def _device_cus():
+    import torch
+    return torch.cuda.get_device_properties(0).multi_processor_count
+
+
+def _tiled_batch(B, W, seed):
+    """W windows (512 distinct ones, repeated) with the oracle's answer for each"""
+    out = rm.synth.make_windows(min(W, 512), B, 4096, 10e6, seed=seed, return_u8=True)
+    reps = (W + 511) // 512
+    iq = np.concatenate([out[0]] * reps)[:W]
+    ri, rf, rp = orc.xcorr_batch_fast(out[0], workers=8)
+    ri, rf, rp = (np.concatenate([a] * reps)[:W] for a in (ri, rf, rp))
+    return iq, ri, rf, rp
+
+
 def test_partial_last_round_goes_through_the_per_transform_kernels(xc, opts):
     """W = k CUs + r windows: the k full rounds run in the fused kernel, the r windows of the last, partial round in the
-    per-transform kernels when the cost model prefers that (the chunk boundary at 4096 windows included); bar against the
-    oracle on every window, integer lags equal to the all-fused run (option small4096 = 0)."""
+    per-transform kernels when the cost model prefers that; bar against the oracle on every window, integer lags equal to the
+    all-fused run (option small4096 = 0).  Host arrays (at most 512 windows: beyond that the pipelined copy path takes the
+    fused kernel for every round) and device pointers; the (8, 4096 + 100) case crosses the chunk boundary at 4096 windows
+    and is driven through device pointers, where the last chunk of 100 windows is a partial round of its own."""
     from radio_mapper_amd import xcorr as x
-    n_cus = 256
-    for B, W in ((8, n_cus + 44), (3, 2 * n_cus + 5), (8, 4096 + 100)):
-        out = rm.synth.make_windows(min(W, 512), B, 4096, 10e6, seed=77 + W, return_u8=True)
-        iq = np.concatenate([out[0]] * ((W + 511) // 512))[:W]
-        ri, rf, rp = orc.xcorr_batch_fast(iq[:512], workers=8)
-        reps = (W + 511) // 512
-        ri, rf, rp = (np.concatenate([a] * reps)[:W] for a in (ri, rf, rp))
+    n_cus = _device_cus()
+    for B, W, dev_ptr in ((8, n_cus + 44, False), (8, n_cus + 44, True), (3, 2 * n_cus + 5, True), (8, 4096 + 100, True)):
+        iq, ri, rf, rp = _tiled_batch(B, W, 77 + W)
+        run = (lambda e: _correlate_dev(e, iq)) if dev_ptr else (lambda e: e.correlate(iq))
         with xc.XcorrEngine(B, 4096, W) as eng:
-            got = eng.correlate(iq)
+            got = run(eng)
         _assert_parity(*got, ri, rf, rp)
         opts("small4096", 0)
         with xc.XcorrEngine(B, 4096, W) as eng:
-            fused = eng.correlate(iq)
+            fused = run(eng)
         x.clear_default_options()
         assert np.array_equal(got[0], fused[0])
-        k = (W // n_cus) * n_cus                      # the full rounds are the same kernel on the same data
+        k = (W // n_cus) * n_cus if W < 4096 else 4096   # the full rounds are the same kernel on the same data
         for a, b in zip(got, fused):
             assert np.array_equal(a[:k], b[:k])
+
+
+@pytest.mark.parametrize("chunk", [16, 100, 300])
+def test_partial_round_with_small_chunks(xc, opts, chunk):
+    """the partial-round split is decided per chunk of windows.  With chunk_windows below the batch's
+    remainder (16 < 44), not a multiple of the CU count (100), or just above it (300) every chunk's own partial round goes
+    to the per-transform kernels or stays in the fused one -- never a window of another chunk, never a spectrum slot beyond
+    the scratch.  Device pointers (the path that takes the split); every window against the oracle, integer lags equal to
+    the all-fused run, and a second call on the same engine identical to the first."""
+    from radio_mapper_amd import xcorr as x
+    n_cus = _device_cus()
+    B, W = 8, n_cus + 44
+    iq, ri, rf, rp = _tiled_batch(B, W, 4242)
+    opts("chunk_windows", chunk)
+    with xc.XcorrEngine(B, 4096, W) as eng:
+        got = _correlate_dev(eng, iq)
+        again = _correlate_dev(eng, iq)
+    _assert_parity(*got, ri, rf, rp)
+    for a, b in zip(got, again):
+        assert np.array_equal(a, b)
+    opts("small4096", 0)
+    with xc.XcorrEngine(B, 4096, W) as eng:
+        fused = _correlate_dev(eng, iq)
+    x.clear_default_options()
+    assert np.array_equal(got[0], fused[0])
+    assert np.allclose(got[1], fused[1], atol=2e-5) and np.allclose(got[2], fused[2], rtol=1e-5)
 
 
 def test_caf_all_hypotheses_in_one_launch(xc):

@@ -151,17 +151,17 @@ def test_engine_failure_is_logged_not_raised(conv, caplog):
 
 def test_partial_or_mismatched_iq_yields_no_measurements(conv, monkeypatch, caplog):
     """Once any detection of a group carries IQ the time tags alone are never used for that group: a group in which
-    only some detections carry IQ, or whose windows differ in length or sample rate, is logged on ...TDoACalculator
-    and yields no measurements (the log-and-return convention of tdoa_processor.py:151-153); the engine is not called,
-    the message is logged once per group, and a group WITHOUT any IQ in the same call still gets the reference's
-    timestamp arithmetic (:166)."""
+    only some detections carry IQ, or whose windows differ in sample rate or are shorter than 16 samples, is logged on
+    ...TDoACalculator and yields no measurements (the log-and-return convention of tdoa_processor.py:151-153); the engine
+    is not called, the message is logged once per group, and a group WITHOUT any IQ in the same call still gets the
+    reference's timestamp arithmetic (:166)."""
     p = _proc(conv)
     called = []
     monkeypatch.setattr(p.tdoa_calculator, "measure_lags", lambda iq, pairs=None: called.append(1))
     dets = _iq_dets(conv, 121.5, seed=4)
     dets[1].iq_samples = None                                        # only some carry IQ
     other = _iq_dets(conv, 156.8, seed=5)
-    other[2].iq_samples = other[2].iq_samples[:32]                   # lengths differ
+    other[2].iq_samples = other[2].iq_samples[:9]                    # one window shorter than the engine's minimum
     third = _iq_dets(conv, 243.0, seed=6)
     third[0].sample_rate_hz = 1.0e6                                  # sample rates differ
     plain = [tp.SignalDetection(d.buoy_id, 406.0, -50, "t", d.gps_timestamp_ns, d.lat, d.lng, 0.9) for d in dets]
@@ -170,7 +170,7 @@ def test_partial_or_mismatched_iq_yields_no_measurements(conv, monkeypatch, capl
             assert p.tdoa_calculator.calculate_tdoa_measurements(group, p.buoy_positions) == []
     assert not called
     msgs = [r.message for r in caplog.records if r.name.endswith("TDoACalculator")]
-    assert len(msgs) == 3 and "Only some detections" in msgs[0] and "differ" in msgs[1] and "differ" in msgs[2]
+    assert len(msgs) == 3 and "Only some detections" in msgs[0] and "too short" in msgs[1] and "differ" in msgs[2]
     caplog.clear()
     seen = {}
     orig = p.hyperbolic_positioner.triangulate_position
@@ -181,6 +181,52 @@ def test_partial_or_mismatched_iq_yields_no_measurements(conv, monkeypatch, capl
     assert not called and list(seen) == [406.0]                      # only the group without IQ is measured ...
     assert seen[406.0] == [1000, 2000, 1000]                         # ... from its time tags alone
     assert len([r for r in caplog.records if r.name.endswith("TDoACalculator")]) == 2   # one line per bad group
+
+
+def test_clipped_excerpts_are_cut_to_a_common_power_of_two(conv, monkeypatch, caplog):
+    """The reference clips an excerpt at the end of the capture buffer (iq_stream_client.py:306-313): a peak in the last
+    128 bins gives e.g. 130 samples beside the other buoys' 256.  Every window keeps its start (what its time tag dates),
+    so the group is correlated on the first 2^k samples that every window holds -- 130 / 256 / 256 -> 128 -- with a
+    warning, instead of yielding nothing; equal lengths that are not a power of two (200) are cut the same
+    way; the reference's wire form (a list of str(complex)) takes the same route; a NaN lag from the engine is refused."""
+    p = _proc(conv)
+    calls = []
+
+    def fake(iq, pairs=None):
+        iq = np.asarray(iq)
+        calls.append(iq)
+        W, B = iq.shape[:2]
+        P = B * (B - 1) // 2
+        return np.full((W, P), 3, np.int32), np.zeros((W, P), np.float32), np.ones((W, P), np.float32)
+
+    monkeypatch.setattr(p.tdoa_calculator, "measure_lags", fake)
+    rng = np.random.default_rng(3)
+    win = [(rng.standard_normal(256) + 1j * rng.standard_normal(256)).astype(np.complex64) for _ in range(3)]
+    dets = _iq_dets(conv, 121.5, seed=7)
+    for d, w in zip(dets, win):
+        d.iq_samples = w
+    dets[2].iq_samples = win[2][:130]                                # clipped at the end of its buffer
+    with caplog.at_level("WARNING"):
+        meas = p.tdoa_calculator.calculate_tdoa_measurements(dets, p.buoy_positions)
+    assert len(meas) == 3 and calls[-1].shape == (1, 3, 128)
+    for b in range(3):
+        assert np.array_equal(calls[-1][0, b], win[b][:128])         # the windows' starts
+    assert any("first 128" in r.message for r in caplog.records)
+    fs = dets[0].sample_rate_hz
+    assert [m.time_difference_ns for m in meas] == [1000 * (j - i) + int(round(3 / fs * 1e9)) for i, j in ((0, 1), (0, 2), (1, 2))]
+    for d, w in zip(dets, win):
+        d.iq_samples = w[:200]                                       # equal, not a power of two
+    assert len(p.tdoa_calculator.calculate_tdoa_measurements(dets, p.buoy_positions)) == 3
+    assert calls[-1].shape == (1, 3, 128)
+    for d, w in zip(dets, win):                                      # the JSON form of the reference's NumpyEncoder
+        d.iq_samples = [str(complex(v)) for v in w[:130 if d is dets[0] else 256]]
+    assert len(p.tdoa_calculator.calculate_tdoa_measurements(dets, p.buoy_positions)) == 3
+    assert calls[-1].shape == (1, 3, 128) and np.allclose(calls[-1][0, 1], win[1][:128])
+    monkeypatch.setattr(p.tdoa_calculator, "measure_lags",
+                        lambda iq, pairs=None: (np.zeros((1, 3), np.int32), np.full((1, 3), np.nan, np.float32), np.ones((1, 3), np.float32)))
+    with caplog.at_level("ERROR"):
+        assert p.tdoa_calculator.calculate_tdoa_measurements(dets, p.buoy_positions) == []
+    assert any("non-finite" in r.message for r in caplog.records)
 
 
 def test_measure_lags_channel_axis_and_engine_cache(monkeypatch):

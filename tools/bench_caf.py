@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import radio_mapper_amd as rm
 from radio_mapper_amd import xcorr
-xcorr.apply_env_options()   # RMX_<KEY>=<int> of the calling shell -> default options (the library reads no environment)
+xcorr.apply_env_options(report=sys.stderr)   # (a refused knob raises) RMX_<KEY>=<int> of the calling shell -> default options (the library reads no environment)
 B, N, W, D = [int(a) for a in sys.argv[1:5]]
 fs = 20e6
 step = 50.0 / fs

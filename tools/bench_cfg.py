@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from radio_mapper_amd import xcorr
-xcorr.apply_env_options()   # RMX_<KEY>=<int> of the calling shell -> default options (the library reads no environment)
+xcorr.apply_env_options(report=sys.stderr)   # (a refused knob raises) RMX_<KEY>=<int> of the calling shell -> default options (the library reads no environment)
 
 def run(B, N, W, reps=9):
     dev = torch.device("cuda", 0)

@@ -2,7 +2,7 @@ import os, sys
 sys.path.insert(0, os.getcwd())
 import torch
 from radio_mapper_amd import xcorr
-xcorr.apply_env_options()   # RMX_<KEY>=<int> of the calling shell -> default options (the library reads no environment)
+xcorr.apply_env_options(report=sys.stderr)   # (a refused knob raises) RMX_<KEY>=<int> of the calling shell -> default options (the library reads no environment)
 def run(W, B=8, N=4096, reps=7, **opts):
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev); g.manual_seed(1)

@@ -13,7 +13,7 @@
 
 #include <type_traits>
 
-#include "fft_r16.hpp"
+#include "../../radio-mapper_amd/csrc/fft_r16.hpp"
 
 namespace rmx {
 namespace pk {

@@ -20,7 +20,8 @@
 
 #include <type_traits>
 
-#include "fft_r16.hpp"
+#include "../../radio-mapper_amd/csrc/fft_r16.hpp"
+#include "../../radio-mapper_amd/csrc/fft_r8.hpp"   // dft8 and its helpers (shared with the generic path)
 
 namespace rmx {
 namespace w8 {
@@ -52,46 +53,6 @@ struct C8 {
     __device__ __forceinline__ void set(int q, float x, float y) { re[q] = x; im[q] = y; }
 };
 
-// ---- radix-8 butterflies --------------------------------------------------------------------------
-// odd half of the radix-2 split, W8^q merged: (u0..u3) -> X[1], X[3], X[5], X[7]  (20 instructions)
-__device__ __forceinline__ void dft4_w8(float2& u0, float2& u1, float2& u2, float2& u3) {
-    const float b1x = u1.x + u1.y, b1y = u1.y - u1.x;   // sqrt(2) u1 W8
-    const float p3 = u3.x + u3.y, q3 = u3.y - u3.x;     // sqrt(2) u3 W8^3 = (q3, -p3)
-    const float sx = b1x + q3, sy = b1y - p3;
-    const float dx = b1x - q3, dy = b1y + p3;
-    const float t0x = u0.x + u2.y, t0y = u0.y - u2.x;   // u0 + (-i) u2
-    const float t1x = u0.x - u2.y, t1y = u0.y + u2.x;
-    u0 = make_float2(fmaf(RMX_RH, sx, t0x), fmaf(RMX_RH, sy, t0y));
-    u2 = make_float2(fmaf(-RMX_RH, sx, t0x), fmaf(-RMX_RH, sy, t0y));
-    u1 = make_float2(fmaf(RMX_RH, dy, t1x), fmaf(-RMX_RH, dx, t1y));
-    u3 = make_float2(fmaf(-RMX_RH, dy, t1x), fmaf(RMX_RH, dx, t1y));
-}
-// after the two half transforms v holds X[0], X[2], X[4], X[6], X[1], X[3], X[5], X[7]: rename to natural order
-__device__ __forceinline__ void dft8_unshuffle(float2 (&v)[8]) {
-    float tx = v[1].x, ty = v[1].y;            // natural[1] <- v4, [4] <- v2, [2] <- v1
-    v[1].x = v[4].x; v[1].y = v[4].y;
-    v[4].x = v[2].x; v[4].y = v[2].y;
-    v[2].x = tx; v[2].y = ty;
-    tx = v[3].x; ty = v[3].y;                  // natural[3] <- v5, [5] <- v6, [6] <- v3
-    v[3].x = v[5].x; v[3].y = v[5].y;
-    v[5].x = v[6].x; v[5].y = v[6].y;
-    v[6].x = tx; v[6].y = ty;
-}
-__device__ __forceinline__ void dft8_stage_a(float2 (&v)[8]) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float2 a = v[q], b = v[q + 4];
-        v[q] = cadd(a, b);
-        v[q + 4] = csub(a, b);
-    }
-}
-// 8-point DFT, X[k] = sum_q v[q] W8^(qk), natural order in and out (52 instructions)
-__device__ __forceinline__ void dft8(float2 (&v)[8]) {
-    dft8_stage_a(v);
-    dft4(v[0], v[1], v[2], v[3]);
-    dft4_w8(v[4], v[5], v[6], v[7]);
-    dft8_unshuffle(v);
-}
 // first layer with the pre-twiddles w[q] merged (v[q] w[q] +- v[q+4] w[q+4]: 10 instructions per pair, 6
 // when w[q] == 1)
 template <bool W0_IS_ONE>

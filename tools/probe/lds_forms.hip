@@ -29,7 +29,7 @@ __global__ void k_sem(int* out, int m0v, int n_words) {
     __syncthreads();
     if (threadIdx.x < 64) {
         float x = 1000.0f + threadIdx.x;
-        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tds_write_addtid_b32 %0 offset:65280\n\ts_waitcnt lgkmcnt(0)" ::"v"(x), "s"(m0v) : "memory");
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tds_write_addtid_b32 %0 offset:65280\n\ts_waitcnt lgkmcnt(0)" ::"v"(x), "s"(m0v) : "memory", "m0");
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -61,7 +61,7 @@ __device__ __forceinline__ void addtid8(int m0v, float a0, float a1, float a2, f
         "ds_write_addtid_b32 %7 offset:%16"
         ::"v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7), "s"(m0v), "n"(O0), "n"(O1), "n"(O2), "n"(O3),
           "n"(O4), "n"(O5), "n"(O6), "n"(O7)
-        : "memory");
+        : "memory", "m0");
 }
 // row position of slot q in the local area: rows of S = {0-3, 12-15} on even positions, the others on odd ones
 constexpr int loc_pos(int q) { return q < 4 ? 2 * q : (q >= 12 ? 2 * (q - 8) : 2 * (q - 4) + 1); }

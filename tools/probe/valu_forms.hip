@@ -91,7 +91,7 @@ __global__ __launch_bounds__(1024) void k(float* out, int iters, float bb, float
                     if ((i & 7) != 0) asm volatile("v_add_f32_e32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
                     else if (MODE == 50) asm volatile("ds_write_b64 %0, %1 offset:0" : : "v"(lds_addr8), "v"(pa[r & 7]) : "memory");
                     else if (MODE == 51) asm volatile("ds_write_b128 %0, %1 offset:0" : : "v"(lds_addr16), "v"(q4) : "memory");
-                    else if (MODE == 52) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tds_write_addtid_b32 %0 offset:0" : : "v"(a[1]), "s"(m0v) : "memory");
+                    else if (MODE == 52) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tds_write_addtid_b32 %0 offset:0" : : "v"(a[1]), "s"(m0v) : "memory", "m0");
                     else if (MODE == 53) asm volatile("ds_read_b64 %0, %1 offset:0" : "=v"(pa[r & 7]) : "v"(lds_addr8) : "memory");
                     else if (MODE == 54) asm volatile("ds_read_b128 %0, %1 offset:0" : "=v"(q4) : "v"(lds_addr16) : "memory");
                     else if (MODE == 55) asm volatile("s_add_u32 %0, %0, 3" : "+s"(sacc) : : "scc");

@@ -2,6 +2,9 @@
 # Profiling recipe for the GPU box (run through gpurun from the repo root):
 #   tools/profile.sh <tag>     -> gpurun_out/prof_<tag>/{stats,pmc_*}  (copy summaries into profiles/)
 # Kernel-trace/stats and every PMC set are separate rocprofv3 runs (never combined).
+# bench.py runs with --profile: the timed path and its parity leg only (no single-group probe, no host-pointer legs, no
+# other shapes), so that counter totals divided by `engine_calls` are the timed path's (traffic_cfg2.json had
+# the probe's 220 one-window calls in its sums).
 set -o pipefail
 #   tools/profile.sh <tag> cfg2   -> the same for another BASELINE shape (bench.py --config), stats + HBM counters only
 tag=${1:-r01}
@@ -10,9 +13,9 @@ out=$PWD/gpurun_out/prof_$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
 if [ "$cfg" = cfg3 ]; then
-  BENCH="python3 $PWD/bench.py --steps 100 --warmup 20 --no-cpu-baseline"
+  BENCH="python3 $PWD/bench.py --steps 100 --warmup 20 --profile"
 else
-  BENCH="python3 $PWD/bench.py --config $cfg --no-cpu-baseline"
+  BENCH="python3 $PWD/bench.py --config $cfg --profile"
 fi
 cd /tmp
 rocprofv3 --kernel-trace --stats -T -f csv -d "$out/stats" -o stats -- $BENCH > "$out/stats.log" 2>&1 || echo "stats run failed"

@@ -17,6 +17,9 @@ import json
 import os
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import source_digest   # noqa: E402  (stdlib-only at import: ties a traffic file to the sources it was taken on)
+
 
 def main():
     src, tag = sys.argv[1], sys.argv[2]
@@ -86,7 +89,8 @@ def main():
             f, w = tot["FETCH_SIZE"] / ncalls["FETCH_SIZE"], tot["WRITE_SIZE"] / ncalls["WRITE_SIZE"]
             traffic = {"kernel": "all kernels of one engine call", "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0,
                        "fetch_size_kib_raw": f, "write_size_kib": w, "engine_calls": ncalls,
-                       "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 64 B per 128-B request)", "tag": tag}
+                       "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 64 B per 128-B request)", "tag": tag,
+                       "source_digest": source_digest()}
             json.dump(traffic, open(os.path.join(out, f"traffic_{cfg}.json"), "w"), indent=1)
             print(traffic)
         print("kernels:", list(pmc))
@@ -97,7 +101,7 @@ def main():
         traffic = {"kernel": dom, "hbm_bytes_per_launch": (2.0 * fetch + write) * 1024.0,
                    "fetch_size_kib_raw": fetch, "write_size_kib": write,
                    "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 64 B per 128-B request)",
-                   "tag": tag}
+                   "tag": tag, "source_digest": source_digest()}
         json.dump(traffic, open(os.path.join(out, "traffic_latest.json"), "w"), indent=1)
         print(traffic)
     print("kernels:", list(pmc))
