@@ -97,14 +97,29 @@ def test_calculator_uses_the_multi_engine_for_several_devices(monkeypatch):
     assert made == [(3, 8, 8, [0, 1]), (3, 8, 8, [0, 1, 2, 3]), (3, 8, 8, 2), (3, 8, 8, 1)]   # (6 windows: capacity 8)
 
 
+def _visible_devices():
+    """device indices for the all-devices case: counted without initialising a device (torch.cuda.device_count() reads
+    sysfs on this image); one entry on a one-GPU box, every card on an 8-GPU node"""
+    try:
+        import torch
+        return list(range(max(torch.cuda.device_count(), 1)))
+    except Exception:
+        return [0]
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("devs", [[0], [0, 0]])
+@pytest.mark.parametrize("devs", [[0], [0, 0], "all"])
 def test_gpu_multi_engine_is_bit_identical_to_the_single_engine(devs):
-    """devices=[0] and the same-device rehearsal devices=[0, 0] (two contexts, two host threads, one GPU) against one
-    XcorrEngine on the same windows: identical arrays, complex64 and raw uint8, default and custom pairs, CAF."""
+    """devices=[0], the same-device rehearsal devices=[0, 0] (two contexts, two host threads, one GPU) and EVERY visible
+    device (one on the build's GPU box; all eight on the driver's node, where this is the first run of MultiXcorrEngine
+    across real devices) against one XcorrEngine on the same windows: identical arrays, complex64 and raw uint8, default
+    and custom pairs, CAF."""
     import __graft_entry__ as g
     g.build()
     from radio_mapper_amd import xcorr
+    if devs == "all":
+        devs = _visible_devices()
+        assert len(devs) == xcorr.device_count()
     W, B, N = 37, 5, 4096
     iq, _, raw = rm.synth.make_windows(W, B, N, 10e6, seed=31, return_u8=True)
     pairs = np.array([(4, 0), (1, 2), (2, 2)], np.int32)
