@@ -709,9 +709,10 @@ def test_whole_window_kernel_by_length(xc, N, B, opts):
 def test_whole_window_scratch_kernel_by_length(xc, N, B, opts):
     """Every other shape with 512 <= L <= 16384 -- more than four buoys, or N = 8192 (the capture length of
     iq_stream_client.py:459) -- runs whole windows in one persistent kernel with the spectra in a per-workgroup
-    scratch (g_win_scr, compiled per length; at L = 16384 one 136 KiB transform per CU, 1024 threads): against the
+    scratch (g_win_scr, compiled per length; at L = 16384 g_win_scr14: one 136 KiB transform per CU, 512 threads x two
+    butterflies per pass; option wscr14 = 0 selects the 1024-thread build): against the
     oracle on complex64 and raw uint8 input, more windows than one pass of the grid on the small lengths, a custom
-    pair list (reversed, repeated, autocorrelation), and the previous path (RMX_WSCR=0: two-kernel LDS path or
+    pair list (reversed, repeated, autocorrelation), and the previous path (option wscr = 0: two-kernel LDS path or
     four-step) on the same input.
     N = 16384 (the capture length of buoy_node.py:364; L = 32768 does not fit the LDS): g_win_eo15 (win_eo.hpp) -- the
     even-bin and odd-bin halves as two LDS-resident 16384-point transforms, the even half's result kept in registers
