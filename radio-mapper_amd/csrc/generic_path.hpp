@@ -1731,9 +1731,25 @@ __global__ __launch_bounds__(1024) void g_cols_inv(const float2* __restrict__ in
     // threads take consecutive columns: the same row segments a tile load would fetch); the last pass never
     // stores r: every output goes into the thread's running (max |r|^2, lowest 'full' index) and leaves only its
     // |r|^2 in the buffer, for the taps and the halo
+#ifdef RMX_EXP_COLS_NOCOMP   // timing experiment only (wrong results): the tile's loads alone, same row segments, 16 in flight per thread
+    {
+        float acc = 0.0f;
+        batched<16>(tid, L1 << kColLogT, nthr,
+                    [&](int E) -> float2 { return src[((E >> kColLogT) << l2) + c0 + (E & (kColT - 1))]; },
+                    [&](int, float2 e) { acc += e.x * e.x + e.y * e.y; });
+        best = acc;
+        bk = tid;
+        x[tid].x = acc;
+    }
+    if (false)
+#endif
     fft_dit_inv<kColLogT>(
         x, l1, twl, tid, nthr,
+#ifdef RMX_EXP_COLS_NOLOAD   // timing experiment only (wrong results): the tile's arithmetic alone, no global loads
+        make_src([&](int E) -> float2 { return make_float2(1e-6f * (float)(E + c0), 1.0f); }),
+#else
         make_src([&](int E) -> float2 { return src[((E >> kColLogT) << l2) + c0 + (E & (kColT - 1))]; }),
+#endif
         make_dst([&](int E0, int off, float2 e) {
             const int E = E0 + off;
             const float v = e.x * e.x + e.y * e.y;
