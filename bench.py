@@ -360,6 +360,26 @@ def other_config(torch, xcorr, name, dev, dev_index, sync_all, cpu_thr):
     return out
 
 
+def job_shard(config, scaling, windows, rank, n_gpus):
+    """(first unit, units of this rank, units of the whole job); a unit = one (window, channel).
+    weak: every rank owns the config's per-GPU batch (`windows` overrides the windows per GPU); strong: the job is the
+    config's batch as BASELINE.json states it -- cfg3: 4096 windows; cfg4: 4096 windows x 10 channels; cfg5: 64 windows;
+    `windows` overrides the total -- block-sharded over the ranks (remainders to the low ranks); at N = 1 one GPU owns it all."""
+    from radio_mapper_amd.shard import window_shard
+    cfg = CONFIGS[config]
+    C = cfg["C"]
+    if scaling == "strong":
+        job = {"cfg4": 4096, "cfg5": 64}.get(config, cfg["W"])
+        total = (windows or job) * C
+        start, count = window_shard(total, rank, n_gpus)
+        return start, count, total
+    per = (windows or cfg["W"]) * C              # channels are a batch axis
+    total = per * n_gpus
+    start, count = window_shard(total, rank, n_gpus)
+    assert count == per
+    return start, count, total
+
+
 OTHER_STEPS = {"cfg1": (50, 10), "cfg2": (20, 5), "cfg4": (20, 5), "cfg5": (3, 1)}   # (timed steps, warm-up) per other shape
 
 
@@ -463,17 +483,7 @@ def main():
     steps, warm = DEFAULT_STEPS[args.config]
     steps = args.steps if args.steps is not None else steps
     warm = args.warmup if args.warmup is not None else warm
-    if args.scaling == "strong":
-        # the job is the config's batch as BASELINE.json states it (cfg3: 4096 windows; cfg4: 4096 windows x 10 channels;
-        # cfg5: 64 windows), block-sharded over the ranks; at N = 1 one GPU owns all of it
-        job = {"cfg4": 4096, "cfg5": 64}.get(args.config, cfg["W"])
-        W_total = (args.windows or job) * C
-        w_start, W = window_shard(W_total, rank, n_gpus)
-    else:
-        W = (args.windows or cfg["W"]) * C        # (window, channel) units per GPU: channels are a batch axis
-        W_total = W * n_gpus
-        w_start, W_rank = window_shard(W_total, rank, n_gpus)
-        assert W_rank == W
+    w_start, W, W_total = job_shard(args.config, args.scaling, args.windows, rank, n_gpus)
     # every rank generates its own block of the job's windows (seed per config, offset by rank)
     sh = Shape(torch, xcorr, args.config, dev, dev_index, W, buoys=args.buoys, seed_offset=7919 * rank)
     B, N, P, D, fs, caf = sh.B, sh.N, sh.P, sh.D, sh.fs, sh.caf

@@ -69,3 +69,19 @@ def test_recorded_traffic_is_refused_when_taken_on_other_sources(tmp_path, monke
     tr, src = bench.recorded_traffic("cfg2")
     assert tr is None and "other sources" in src
     assert bench.recorded_traffic("cfg4") == (None, None)
+
+
+def test_job_shard_weak_and_strong():
+    """--scaling weak: every rank a full per-GPU batch; --scaling strong: BASELINE's job block-sharded over the ranks
+    (cfg3 4096 windows, cfg4 4096 x 10 channels, cfg5 64 windows), blocks contiguous and complete."""
+    import bench
+    assert bench.job_shard("cfg3", "weak", None, 3, 8) == (3 * 4096, 4096, 8 * 4096)
+    assert bench.job_shard("cfg4", "weak", None, 0, 2) == (0, 5120, 10240)
+    for cfg, total in (("cfg3", 4096), ("cfg4", 40960), ("cfg5", 64)):
+        for n in (1, 2, 3, 8):
+            blocks = [bench.job_shard(cfg, "strong", None, r, n) for r in range(n)]
+            assert all(b[2] == total for b in blocks)
+            assert blocks[0][0] == 0 and sum(b[1] for b in blocks) == total
+            assert all(blocks[r + 1][0] == blocks[r][0] + blocks[r][1] for r in range(n - 1))
+            assert max(b[1] for b in blocks) - min(b[1] for b in blocks) <= 1
+    assert bench.job_shard("cfg5", "strong", 16, 1, 2) == (8, 8, 16)

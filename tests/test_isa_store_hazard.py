@@ -94,3 +94,56 @@ def test_fused_kernel_keeps_its_registers_and_uses_no_scratch(tmp_path):
         assert f["vgpr_count"] <= 256, (n, f)        # two waves per SIMD of the 512-register file
         assert f["max_flat_workgroup_size"] == 512, (n, f)
     print(seen)
+
+
+@pytest.mark.skipif(not os.path.exists(OBJDUMP), reason="no llvm-objdump")
+def test_m0_in_the_fused_kernel_is_written_before_every_use(tmp_path):
+    """loc_write4 (fft_r16.hpp) writes M0 inside an asm statement -- it now says so in its clobber list.  M0 has
+    two users in k_win, and both write it themselves right in front of their reads: the statement's own `s_mov_b32 m0, sN`
+    + ds_write_addtid_b32 stores, and the peak search's indexed register read (`s_set_gpr_idx_on sN` ... `s_set_gpr_idx_off`,
+    which loads the index into M0: a bracket of at most four instructions with no LDS store inside).  Nothing else may
+    depend on M0: no movrel, no LDS-DMA, no GWS, no sendmsg payload, no instruction naming m0 other than that s_mov."""
+    import __graft_entry__ as g
+    g.build()
+    lib = os.path.join(ROOT, "radio-mapper_amd", "csrc", "librmx_hip.so")
+    work = str(tmp_path)
+    shutil.copy(lib, os.path.join(work, "lib.so"))
+    subprocess.run([OBJDUMP, "--offloading", "lib.so"], cwd=work, check=True, capture_output=True)
+    objs = [f for f in os.listdir(work) if "gfx950" in f]
+    assert objs
+    dis = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", objs[0]], cwd=work, check=True, capture_output=True,
+                         text=True).stdout
+    kernels = {}
+    cur = None
+    for ln in dis.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", ln)
+        if m:
+            cur = m.group(1) if "k_winILb" in m.group(1) else None
+            if cur:
+                kernels[cur] = []
+            continue
+        if cur:
+            t = ln.split("//")[0].strip()
+            if t:
+                kernels[cur].append(t)
+    assert len(kernels) == 2, list(kernels)
+    implicit = re.compile(r"^(v_movrel|s_movrel|v_interp|ds_gws|s_sendmsg|ds_ordered|ds_append|ds_consume|buffer_load\S* .*\blds\b|global_load_lds)")
+    for name, ins in kernels.items():
+        named = [t for t in ins if re.search(r"\bm0\b", t)]
+        assert named and all(re.fullmatch(r"s_mov_b32 m0, s\d+", t) for t in named), (name, [t for t in named if not t.startswith("s_mov_b32 m0")][:5])
+        assert not [t for t in ins if implicit.match(t)], name
+        n_addtid = sum(t.startswith("ds_write_addtid_b32") for t in ins)
+        assert n_addtid >= 64 and n_addtid <= 8 * len(named), (name, n_addtid, len(named))
+        # every addtid store sits behind an s_mov m0 of its own statement: walking back from it, the s_mov comes before
+        # any gpr-index bracket does
+        for k, t in enumerate(ins):
+            if t.startswith("ds_write_addtid_b32"):
+                j = k - 1
+                while j >= 0 and not ins[j].startswith(("s_mov_b32 m0", "s_set_gpr_idx")):
+                    j -= 1
+                assert j >= 0 and ins[j].startswith("s_mov_b32 m0"), (name, k, ins[max(j, 0)])
+            if t.startswith("s_set_gpr_idx_on"):
+                window = ins[k + 1:k + 5]
+                assert any(w.startswith("s_set_gpr_idx_off") for w in window), (name, window)
+                inside = window[:next(i for i, w in enumerate(window) if w.startswith("s_set_gpr_idx_off"))]
+                assert not any(w.startswith("ds_") for w in inside), (name, inside)
