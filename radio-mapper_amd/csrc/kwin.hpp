@@ -709,7 +709,11 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
             int pi = hi, ps = hs + 1;
             if (ps >= B - 1 - pi) { ++pi; ps = 0; }
             const bool valid = pi + 1 < B;
+#ifdef RMX_KWIN_FORCE_ANCHOR   // timing experiment (results unchanged): the anchor spectrum is requested again for EVERY pair -- the
+            const bool new_anchor = valid;   // scratch traffic of a design that cannot keep its anchor resident (LABNOTES R4.6)
+#else
             const bool new_anchor = valid && pi != hi;
+#endif
 #ifndef RMX_KWIN_REQ_BRANCHY
             // Every instruction costs the issuing wave ~2 ns whatever its kind (tools/probe/valu_forms.hip), and the two
             // uniform branches around each of the eight requests were 45 scalar instructions per pair plus the vector

@@ -34,6 +34,9 @@
 #endif
 #include "generic_path.hpp"
 #include "win_eo.hpp"
+#ifdef RMX_EXPERIMENTS
+#include "../../tools/experiments/kwin8k.hpp"   // N = 8192 on k_win's network: parity-green, not faster (LABNOTES.md R4.6)
+#endif
 #include "detect_path.hpp"
 
 namespace rmx {
@@ -677,6 +680,9 @@ struct rmx_ctx {
     float4* g_ws_scratch = nullptr;
     float2* g_tw_win = nullptr;            // W_L half table of that kernel
     float2* g_tw_l = nullptr;              // g_win_eo15 (N = 16384): W_32768^i, i < 1024
+    bool g_k8 = false;                     // N = 8192: k_win8k (kwin8k.hpp) instead of g_win_scr14 for batches that fill the chip
+    float4* g_k8_tw1 = nullptr;            // its TW1 tables (both halves)
+    float2* g_k8_tw2 = nullptr;            // k_win's TW2 table
     const void* g_cols_inv_fn = nullptr;
     const void* g_cols_fwd_fn[2] = {nullptr, nullptr};   // [u8]
     const void* g_rows_inv_fn = nullptr;
@@ -1094,6 +1100,25 @@ static int generic_init(rmx_ctx* c) {
         const size_t sbytes = (size_t)grid * c->g_ws_upw * c->n_buoys * L * 8;
         RMX_HIP(c, hipMalloc((void**)&c->g_ws_scratch, sbytes));
         c->scratch_bytes += sbytes;
+#ifdef RMX_EXPERIMENTS
+        // N = 8192: the two bin-parity halves on the fused N = 4096 kernel's network (k_win8k), same scratch size
+        // (B x 2 x 64 KiB per persistent workgroup), one workgroup per CU; experiments build, option kwin8k = 1
+        if (c->g_logL == 14 && c->knobs.get_or("kwin8k", 0) != 0) {
+            std::vector<float4> t1;
+            std::vector<float4> t1_4096;
+            std::vector<float2> t2;
+            build_tables(t1_4096, t2);
+            k8::build_tables8k(t1);
+            RMX_HIP(c, hipMalloc((void**)&c->g_k8_tw1, t1.size() * sizeof(float4)));
+            RMX_HIP(c, hipMemcpy(c->g_k8_tw1, t1.data(), t1.size() * sizeof(float4), hipMemcpyHostToDevice));
+            RMX_HIP(c, hipMalloc((void**)&c->g_k8_tw2, t2.size() * sizeof(float2)));
+            RMX_HIP(c, hipMemcpy(c->g_k8_tw2, t2.data(), t2.size() * sizeof(float2), hipMemcpyHostToDevice));
+            c->scratch_bytes += t1.size() * sizeof(float4) + t2.size() * sizeof(float2);
+            RMX_HIP(c, hipFuncSetAttribute((const void*)k8::k_win8k<false>, hipFuncAttributeMaxDynamicSharedMemorySize, k8::kLds8Bytes));
+            RMX_HIP(c, hipFuncSetAttribute((const void*)k8::k_win8k<true>, hipFuncAttributeMaxDynamicSharedMemorySize, k8::kLds8Bytes));
+            c->g_k8 = c->g_ws_upw == 1 && grid <= c->n_cus;      // (its grid is the scratch's: one window slot per workgroup)
+        }
+#endif
     }
     // windows per chunk (host_plan.hpp: spectra + products under 32 GiB of the 288, "gen_chunk" caps it for experiments)
     const long chunk = host::generic_chunk_windows(c->n_buoys, L, c->max_windows, 32L << 30, c->knobs.get_or("gen_chunk", 0));
@@ -1328,6 +1353,24 @@ static int generic_batch(rmx_ctx* c, const void* d_iq, int n_windows, int n_pair
         const gen::GPair* a_pairs = c->g_pairs;
         long grid = ((long)n_windows + c->g_ws_upw - 1) / c->g_ws_upw;
         if (grid > c->g_ws_grid) grid = c->g_ws_grid;
+#ifdef RMX_EXPERIMENTS
+        const bool def_list = c->plan_all_pairs && n_pairs == c->n_buoys * (c->n_buoys - 1) / 2;
+        if (c->g_k8 && (def_list || n_pairs <= k8::kMaxPairs8)) {   // N = 8192 on k_win's network (kwin8k.hpp)
+            const float out_scale = std::ldexp(1.0f, 3 * kTw1ScaleLog2 - 14);
+            const k8::Pair2* prs = def_list ? nullptr : reinterpret_cast<const k8::Pair2*>(c->g_pairs);
+            const int stag = (int)c->knobs.get_or("stag", 1);
+            if (u8)
+                hipLaunchKernelGGL(k8::k_win8k<true>, dim3((unsigned)grid), dim3(kThreads), k8::kLds8Bytes, c->stream, d_iq,
+                                   c->g_ws_scratch, c->g_k8_tw1, c->g_k8_tw2, c->n_buoys, prs, n_pairs, 0L, out_scale, d_lag,
+                                   d_frac, d_peak, n_windows, stag);
+            else
+                hipLaunchKernelGGL(k8::k_win8k<false>, dim3((unsigned)grid), dim3(kThreads), k8::kLds8Bytes, c->stream, d_iq,
+                                   c->g_ws_scratch, c->g_k8_tw1, c->g_k8_tw2, c->n_buoys, prs, n_pairs, 0L, out_scale, d_lag,
+                                   d_frac, d_peak, n_windows, stag);
+            RMX_HIP(c, hipGetLastError());
+            return RMX_OK;
+        }
+#endif
         if (logL == 15) {                          // g_win_eo15: one more table
             const float2* a_twl = c->g_tw_l;
             void* args[] = {&a_iq, &a_scr, &a_tw, &a_twl, &a_nb, &a_nw, &a_first, &a_fs, &a_os, &a_pairs, &a_np, &d_lag, &d_frac, &d_peak};
@@ -1494,7 +1537,7 @@ void rmx_destroy(rmx_ctx* c) {
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     for (void* p : {(void*)c->g_tw, (void*)c->g_tw1, (void*)c->g_tw2, (void*)c->g_thi, (void*)c->g_tlo, (void*)c->g_spec,
                     (void*)c->g_spec_r, (void*)c->g_prod, (void*)c->g_rec, (void*)c->g_halo, (void*)c->g_pairs,
-                    (void*)c->g_ws_scratch, (void*)c->g_tw_win, (void*)c->g_tw_l})
+                    (void*)c->g_ws_scratch, (void*)c->g_tw_win, (void*)c->g_tw_l, (void*)c->g_k8_tw1, (void*)c->g_k8_tw2})
         if (p) (void)hipFree(p);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     for (hipEvent_t e : c->copy_ev)

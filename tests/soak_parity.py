@@ -146,6 +146,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=240.0)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--max-bytes", type=float, default=3.0e8, help="largest input batch in bytes (complex64)")
+    ap.add_argument("--device-pointers", action="store_true", help="half of the cases through RMX_IN_DEVICE | RMX_OUT_DEVICE (needs torch)")
     ap.add_argument("--caf", action="store_true", help="soak rmx_caf_batch (Doppler grid) instead of rmx_xcorr_batch")
     ap.add_argument("--detect", action="store_true", help="soak rmx_detect_batch (spectral detection) against oracle/detect_ref.py")
     args = ap.parse_args()
@@ -175,7 +176,7 @@ def main():
         B = int(rng.choice([2, 3, 3, 4, 5, 6, 8, 8, 9, 12, 16])) if logn <= 14 else int(rng.choice([2, 3, 4, 6, 8]))
         per_win = B * N * 8
         w_max = max(1, int(args.max_bytes // per_win))
-        W = int(min(w_max, rng.choice([1, 2, 3, 7, 16, 61, 256, 300, 1024])))
+        W = int(min(w_max, rng.choice([1, 2, 3, 7, 16, 61, 256, 300, 1024] + ([257, 300, 517, 600, 1100] if N == 4096 else []))))
         u8 = bool(rng.integers(0, 2))
         snr = float(rng.choice([10.0, 10.0, 3.0, 0.0, 20.0]))
         fs = float(rng.choice([2.4e6, 10e6, 20e6]))
@@ -190,12 +191,36 @@ def main():
         seed = int(rng.integers(1, 2 ** 31 - 1))
         out = rm.synth.make_windows(W, B, N, fs, seed=seed, snr_db=snr, return_u8=u8)
         iq, raw = (out[0], out[2]) if u8 else (out[0], None)
+        # (round 4) N = 4096: a third of the cases run with a small or odd chunk size, and half of the default-pair-list
+        # cases through device pointers -- the combination that takes the per-chunk partial-round split of rmx_xcorr_batch
+        chunk = 0
+        if N == 4096 and rng.integers(0, 3) == 0:
+            chunk = int(rng.choice([8, 16, 104, 256, 304, 1000]))
+            xcorr.set_default_option("chunk_windows", chunk)
+        dev_ptr = args.device_pointers and bool(rng.integers(0, 2))
         t0 = time.time()
         eng = xcorr.XcorrEngine(B, N, W)
         try:
-            li, lf, pk = eng.correlate(raw if u8 else iq, pairs)
+            if dev_ptr:
+                import torch
+                dev = torch.device("cuda", 0)
+                src = raw if u8 else iq.view(np.float32)
+                xd = torch.from_numpy(np.ascontiguousarray(src)).to(dev)
+                Pn = B * (B - 1) // 2 if pairs is None else len(pairs)
+                lagd = torch.zeros((W, Pn), dtype=torch.int32, device=dev)
+                fracd = torch.zeros((W, Pn), dtype=torch.float32, device=dev)
+                peakd = torch.zeros((W, Pn), dtype=torch.float32, device=dev)
+                eng.set_stream(torch.cuda.current_stream().cuda_stream)
+                eng.correlate_device(xd.data_ptr(), W, lagd.data_ptr(), fracd.data_ptr(), peakd.data_ptr(), pairs, u8=u8)
+                torch.cuda.synchronize()
+                li, lf, pk = lagd.cpu().numpy(), fracd.cpu().numpy(), peakd.cpu().numpy()
+                del xd, lagd, fracd, peakd
+            else:
+                li, lf, pk = eng.correlate(raw if u8 else iq, pairs)
         finally:
             eng.close()
+            if chunk:
+                xcorr.clear_default_options()
         t_gpu = time.time() - t0
         ri, rf, rp = orc.xcorr_batch_fast(iq, pairs, workers=8)
         bad = li != ri
@@ -235,7 +260,7 @@ def main():
         worst_peak = max(worst_peak, float(peak_err))
         by_n[N] = by_n.get(N, 0) + li.size
         print(f"case {case:4d}  N={N:7d} B={B:2d} W={W:5d} {'u8 ' if u8 else 'c64'} snr={snr:4.1f} "
-              f"pairs={'all' if pairs is None else len(pairs):>4} seed={seed:10d}  pair-windows={li.size:7d} "
+              f"pairs={'all' if pairs is None else len(pairs):>4} {'dev' if dev_ptr else 'hst'} chunk={chunk:4d} seed={seed:10d}  pair-windows={li.size:7d} "
               f"int-mismatch={int(bad.sum())} (excused {int(excused.sum())})  lag_err={lag_err:.2e} peak_err={peak_err:.2e} "
               f"gpu={t_gpu * 1e3:7.1f} ms{'  (%d flat-peak lags within 4 ulp of the taps)' % ill if ill else ''}{'  FAIL' if unexcused or tol_fail else ''}", flush=True)
     print(f"SUMMARY: {n_cases} cases, {n_pw} pair-windows, {n_bad} failures, {n_excused} excused near-ties, {n_ill} flat-peak lags beyond 1e-5 but within 4 ulp of the oracle's taps, "
