@@ -11,6 +11,15 @@
 
 #include "fft_r16.hpp"
 
+// cache policy of the spectrum scratch accesses (buffer instruction aux bits on gfx950: 1 = sc0, 2 = sc1, 4 = nt); A/B'd in
+// tools/probe/kwin_bench.hip (LABNOTES R4.7): the default policy stays
+#ifndef RMX_KWIN_LOAD_AUX
+#define RMX_KWIN_LOAD_AUX 0
+#endif
+#ifndef RMX_KWIN_STORE_AUX
+#define RMX_KWIN_STORE_AUX 0
+#endif
+
 namespace rmx {
 
 using u32x4 = unsigned int __attribute__((ext_vector_type(4)));
@@ -359,7 +368,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
         asm volatile("" : "+s"(bo));
 #pragma unroll
         for (int j = J0; j < J1; ++j) {
-            const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(ss, soff, bo + j * (kThreads * 16), 0);
+            const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(ss, soff, bo + j * (kThreads * 16), RMX_KWIN_LOAD_AUX);
             d.set(2 * j, __uint_as_float(w.x), __uint_as_float(w.y));
             d.set(2 * j + 1, __uint_as_float(w.z), __uint_as_float(w.w));
         }
@@ -382,7 +391,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
             // (an asm that keeps e0..e3 live) were right 200 calls out of 200, as is this immediate-soffset form, for
             // which the compiler inserts the s_nop itself.  (The SGPR form alone is fine: the probe, whose stores
             // do not reuse their data registers, has no wrong float.)
-            __builtin_amdgcn_raw_buffer_store_b128(w, ss, soff + (b * 8 + j) * (kThreads * 16), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(w, ss, soff + (b * 8 + j) * (kThreads * 16), 0, RMX_KWIN_STORE_AUX);
         }
     };
     // forward spectrum of the samples in x, in place (carries the 2^-6 of the TW1 table)

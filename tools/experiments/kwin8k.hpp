@@ -294,10 +294,12 @@ __global__ __launch_bounds__(kThreads, 2) void k_win8k(const void* __restrict__ 
                              "+v"(x[q + 2].y), "+v"(x[q + 3].x), "+v"(x[q + 3].y));
             {   // the next transform's samples travel during this one (the sample registers are free behind the fold)
                 const int nb = b + 1 < B ? b + 1 : 0;
+#ifndef K8_NO_SAMPLE
                 if (b + 1 < B || h == 0) {
                     load_x(sa, nb, 0);
                     load_x(sb, nb, kN8 / 2);
                 }
+#endif
             }
             twist(x, h);
             dft16(x);
@@ -311,7 +313,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_win8k(const void* __restrict__ 
             wave_lds_order();
             loc_read16(smem + (seq & 1) * kLdsWinImg + loc_rd, x);
             dft16_tw_row(x, tw2row, r0, r1);
+#ifndef K8_NO_STORE
             store_spec(x, 2 * b + h);
+#endif
             ++seq;
         }
     }
