@@ -110,7 +110,7 @@ KWB_V2(launch_a15, 1, 15)
 struct Variant { const char* name; launch_fn fn; const void* kfn; int lds; };
 
 int main(int argc, char** argv) {
-    const int W = argc > 1 ? atoi(argv[1]) : 4096, B = 8, N = kM;
+    const int W = argc > 1 ? atoi(argv[1]) : 4096, B = argc > 4 ? atoi(argv[4]) : 8, N = kM;
     const int reps = argc > 2 ? atoi(argv[2]) : 200, warm = argc > 3 ? atoi(argv[3]) : 150;
     const int P = B * (B - 1) / 2;
     Bufs b{};
