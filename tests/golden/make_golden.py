@@ -13,6 +13,8 @@ It imports ``/root/reference/tdoa_processor.py`` and records
   order (``tdoa_processor.py:156-157``), reduced by the path's spec (SURVEY.md §8a-spec S4-S6:
   ``np.abs`` -> ``np.argmax`` -> 3-point parabola).  Small cases store their inputs (as the raw
   uint8 I/Q that decodes to them); large cases store the generator seed + an input checksum.
+  ``--r04-only`` writes just the fixture added in round 4 (``xcorr_b3_n8192``: the capture length of
+  ``iq_stream_client.py:459``).
 * ``caf_*.npz`` -- the same primitive over a Doppler grid (``run_caf_case``); ``--caf-only``
   regenerates just these.
 * ``triangulate_position.json`` -- ``HyperbolicPositioning.triangulate_position`` on deterministic
@@ -256,6 +258,16 @@ def main():
     import scipy
     meta = dict(numpy=np.__version__, scipy=scipy.__version__,
                 primitive="tdoa_processor.correlate(x_j, x_i, mode='full', method='fft')")
+    if "--r04-only" in sys.argv:
+        # round 4: the streaming client's capture length (iq_stream_client.py:459: 8192 samples), which had no fixture of
+        # its own; written without touching the files of the earlier rounds
+        for name, kw in [("xcorr_b3_n8192", dict(n_windows=2, n_buoys=3, n_samples=8192, sample_rate_hz=2.4e6, seed=15))]:
+            iq, delays, raw = rm.synth.make_windows(return_u8=True, **kw)
+            res = run_case(ref, iq)
+            np.savez_compressed(os.path.join(HERE, name + ".npz"), raw_u8=raw, delays=delays,
+                                sample_rate_hz=kw["sample_rate_hz"], **res)
+            print(name, "min margin %.3e" % res["margin"].min())
+        return
 
     small = [
         ("xcorr_b3_n1024", dict(n_windows=2, n_buoys=3, n_samples=1024, sample_rate_hz=2.4e6, seed=11)),
@@ -263,6 +275,7 @@ def main():
         ("xcorr_b8_n4096", dict(n_windows=4, n_buoys=8, n_samples=4096, sample_rate_hz=10e6, seed=1003)),
         ("xcorr_b4_n256", dict(n_windows=3, n_buoys=4, n_samples=256, sample_rate_hz=2.048e6, seed=13)),
         ("xcorr_b3_n16384", dict(n_windows=1, n_buoys=3, n_samples=16384, sample_rate_hz=2.048e6, seed=14)),
+        ("xcorr_b3_n8192", dict(n_windows=2, n_buoys=3, n_samples=8192, sample_rate_hz=2.4e6, seed=15)),   # (round 4)
     ]
     for name, kw in small:
         iq, delays, raw = rm.synth.make_windows(return_u8=True, **kw)

@@ -77,18 +77,24 @@ def test_golden_fixtures(xc, golden_dir, name):
         assert np.array_equal(li, li8) and np.array_equal(lf, lf8) and np.array_equal(pk, pk8)
 
 
-@pytest.mark.parametrize("name", ["xcorr_b4_n256", "xcorr_b3_n1024", "xcorr_b3_n16384"])
-def test_golden_fixtures_other_lengths(xc, golden_dir, name):
-    """Window lengths other than 4096 run the generic path (LDS radix-2 for L <= 8192, four-step
-    through HBM above): same definition, same bar."""
+@pytest.mark.parametrize("name", ["xcorr_b4_n256", "xcorr_b3_n1024", "xcorr_b3_n16384", "xcorr_b3_n8192"])
+def test_golden_fixtures_other_lengths(xc, golden_dir, name, opts):
+    """Window lengths other than 4096 run the generic path: same definition, same bar, against fixtures generated from
+    the reference module (xcorr_b3_n8192 and xcorr_b3_n16384 are the reference's own capture lengths,
+    iq_stream_client.py:459 and buoy_node.py:364).  Twice: with the dispatch a batch of this size gets (few windows: the
+    per-transform / four-step kernels), and with the whole-window kernels forced (option wscr = 2: g_win_scr,
+    g_win_scr14, g_win_eo15 -- what a batch that fills the chip runs); no exception for these fixtures in either."""
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     iq = orc.decode_u8_iq(g["raw_u8"])
     W, B, N = iq.shape
-    with xc.XcorrEngine(B, N, W) as eng:
-        li, lf, pk = eng.correlate(iq)
-        _assert_parity(li, lf, pk, g["lag_int"], g["lag_frac"], g["peak"], g["margin"])
-        li8, lf8, pk8 = eng.correlate(g["raw_u8"])
-        assert np.array_equal(li, li8) and np.array_equal(lf, lf8) and np.array_equal(pk, pk8)
+    for force in (False, True):
+        if force:
+            opts("wscr", 2)
+        with xc.XcorrEngine(B, N, W) as eng:
+            li, lf, pk = eng.correlate(iq)
+            _assert_parity(li, lf, pk, g["lag_int"], g["lag_frac"], g["peak"], g["margin"])
+            li8, lf8, pk8 = eng.correlate(g["raw_u8"])
+            assert np.array_equal(li, li8) and np.array_equal(lf, lf8) and np.array_equal(pk, pk8)
 
 
 def test_edge_cases_n256_fixture(xc, golden_dir):

@@ -10,7 +10,7 @@ import pytest
 import radio_mapper_amd as rm
 from oracle import xcorr_ref as orc
 
-SMALL = ["xcorr_b3_n1024", "xcorr_b3_n4096", "xcorr_b8_n4096", "xcorr_b4_n256", "xcorr_b3_n16384"]
+SMALL = ["xcorr_b3_n1024", "xcorr_b3_n4096", "xcorr_b8_n4096", "xcorr_b4_n256", "xcorr_b3_n16384", "xcorr_b3_n8192"]
 
 
 def _load(golden_dir, name):
