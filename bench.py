@@ -236,6 +236,42 @@ def recorded_traffic(config):
         f"digest {now}; recorded by tools/profile.sh, not measured in this run)")
 
 
+def recorded_counters(launch_ms):
+    """SQ / LDS / L2 counters per launch of the fused kernel from profiles/pmc_latest.json (tools/profile.sh passes, same
+    digest rule as the traffic figure) as the utilisation ratios SURVEY.md section 8d asks for beside the HBM fraction."""
+    pj = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    if not os.path.exists(pj):
+        return None
+    try:
+        d = json.load(open(pj))
+    except Exception:
+        return None
+    if d.get("source_digest") != source_digest():
+        return {"stale": f"profiles/pmc_latest.json (tag {d.get('tag')}) was recorded on other sources; re-run tools/profile.sh"}
+    c = d["counters"]
+    wc = c.get("SQ_WAVE_CYCLES") or 0.0
+    out = {"source": f"profiles/pmc_latest.json (tag {d.get('tag')}): rocprofv3 --pmc passes of bench.py --profile, per launch of {d.get('kernel')}",
+           "valu_wave_instructions": c.get("SQ_INSTS_VALU"), "lds_wave_instructions": c.get("SQ_INSTS_LDS"),
+           "salu_wave_instructions": c.get("SQ_INSTS_SALU")}
+    if wc:
+        out["valu_active_frac_of_wave_cycles"] = c.get("SQ_ACTIVE_INST_VALU", 0.0) / wc   # saturates near 0.5 at two waves per SIMD
+        out["wait_any_frac"] = c.get("SQ_WAIT_ANY", 0.0) / wc
+        out["wait_inst_any_frac"] = c.get("SQ_WAIT_INST_ANY", 0.0) / wc
+        out["wait_inst_lds_frac"] = c.get("SQ_WAIT_INST_LDS", 0.0) / wc
+    if c.get("SQ_INSTS_VALU") and launch_ms:
+        # plain VALU issue time at the measured 1.13 ns per wave-instruction and SIMD (tools/probe/valu_forms.hip), 1024 SIMDs;
+        # DPP / compare forms cost more: DESIGN.md section 7 puts the weighted figure at 0.70
+        out["fp32_valu_issue_frac_of_launch_lower_bound"] = c["SQ_INSTS_VALU"] * 1.13e-6 / 1024.0 / launch_ms
+    if c.get("SQ_LDS_IDX_ACTIVE") and c.get("GRBM_GUI_ACTIVE"):
+        # (GRBM_GUI_ACTIVE sums the busy cycles of the 8 XCDs, SQ_LDS_IDX_ACTIVE the LDS-array cycles of the 256 CUs)
+        out["lds_busy_frac"] = c["SQ_LDS_IDX_ACTIVE"] / (c["GRBM_GUI_ACTIVE"] / 8.0 * 256.0)
+        out["shader_clock_ghz"] = c["GRBM_GUI_ACTIVE"] / 8.0 / (launch_ms * 1e6) if launch_ms else None
+        out["lds_bank_conflict_frac_of_lds_cycles"] = c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"]
+    if c.get("TCC_HIT_sum") is not None and c.get("TCC_MISS_sum"):
+        out["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
+    return out
+
+
 class Shape:
     """One BASELINE shape on one device: synthetic windows resident in HBM, an engine, a step."""
 
@@ -667,8 +703,9 @@ def main():
                          "pair_kernel_ms_per_step": pair_ms / n_meas,
                          "whole_path_frac": alg_bytes_per_step_gpu / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "whole_path_frac_cold": alg_bytes_per_step_gpu / (ms_per_step_cold * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "fp32_valu_and_lds": "DESIGN.md section 6 (profiles/*_pmc.json): the fused kernel is bound by fp32 VALU "
-                                              "issue (70 % of the launch), not by HBM; SQ counters per launch are recorded there"},
+                         "counters": recorded_counters(launch_ms) if fused else None,
+                         "fp32_valu_and_lds": "DESIGN.md section 7: the fused kernel is bound by fp32 VALU issue (70 % of the launch "
+                                              "with DPP / compare forms weighted), not by HBM"},
             "ingest_samples_per_s": ingest,
             "realtime_factor": ingest / (B * fs),               # seconds of every buoy's signal processed per second
             "host_path_ms_per_step": host_ms,

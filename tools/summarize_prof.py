@@ -104,6 +104,11 @@ def main():
                    "tag": tag, "source_digest": source_digest()}
         json.dump(traffic, open(os.path.join(out, "traffic_latest.json"), "w"), indent=1)
         print(traffic)
+    if dom:
+        # the dominant kernel's counters per launch, tied to the sources like the traffic figure: bench.py reports ratios of
+        # them in roofline.counters (fp32-VALU and LDS utilisation beside the HBM fraction)
+        json.dump({"kernel": dom, "counters": pmc[dom], "tag": tag, "source_digest": source_digest()},
+                  open(os.path.join(out, "pmc_latest.json"), "w"), indent=1, sort_keys=True)
     print("kernels:", list(pmc))
 
 
