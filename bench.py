@@ -265,7 +265,6 @@ def recorded_counters(launch_ms):
     if c.get("SQ_LDS_IDX_ACTIVE") and c.get("GRBM_GUI_ACTIVE"):
         # (GRBM_GUI_ACTIVE sums the busy cycles of the 8 XCDs, SQ_LDS_IDX_ACTIVE the LDS-array cycles of the 256 CUs)
         out["lds_busy_frac"] = c["SQ_LDS_IDX_ACTIVE"] / (c["GRBM_GUI_ACTIVE"] / 8.0 * 256.0)
-        out["shader_clock_ghz"] = c["GRBM_GUI_ACTIVE"] / 8.0 / (launch_ms * 1e6) if launch_ms else None
         out["lds_bank_conflict_frac_of_lds_cycles"] = c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"]
     if c.get("TCC_HIT_sum") is not None and c.get("TCC_MISS_sum"):
         out["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
