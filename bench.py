@@ -12,10 +12,14 @@ A step = one pass of the hot path (IQ windows -> per-pair lags) over one batch o
 Windows shard across ranks with no data-path collective -- `--scaling weak` (default): every rank owns a full
 batch; `--scaling strong`: the config's windows are block-sharded over the ranks (radio_mapper_amd.shard.window_shard,
 as BASELINE.json words cfg3/cfg4/cfg5) -- and rank 0 gathers the per-pair lag scalars once after the timed region.
-One JSON line is printed by rank 0.  At N = 1 the default run also times the other four BASELINE shapes in the same
-process (`other_configs`, a bounded number of steps each; `--no-other-configs` skips them) and reports the headline
-shape without the untimed pre-warm (`ms_per_step_cold`), its ingest rate and real-time factor, and the host-pointer
-path for complex64 and raw uint8 input.
+One JSON line is printed by rank 0.  Headline figures (`ms_per_step`, `value`, `roofline`) come from the region that
+follows EXACTLY `--warmup` steps of the headline shape; the same K steps after an untimed pre-warm are reported beside
+them as `ms_per_step_sustained` (+ `prewarm_steps`).  At N = 1 the default run also times the other four BASELINE
+shapes in the same process (`other_configs`, a bounded number of steps each, with per-kernel-family times;
+`--no-other-configs` skips them) and a one-GPU projection of the 1 -> 8 GPU strong-scaling curve
+(`strong_scaling_projection`) -- both run BEFORE the headline region (`region_order` says so) -- and reports the ingest
+rate, the real-time factor, and the host-pointer path for complex64 and raw uint8 input.  The line names the binary
+that ran (`build.binary_digest`) beside the digest of the sources it sees and the run refuses to start on a mismatch.
 
 Multi-GPU: `python bench.py --gpus N` with WORLD_SIZE unset starts its own N ranks
 (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`) as a CHILD process
@@ -204,17 +208,12 @@ def cpu_baseline(get_windows, W, B, N, budget_s, doppler=None):
 
 
 def source_digest():
-    """sha256 over the kernel sources the library is built from (the same list __graft_entry__.build() watches): ties a
-    recorded profiles/traffic_*.json to the code it was measured on (tools/summarize_prof.py writes it, bench.py refuses a
-    figure whose digest is not the current one)."""
-    import hashlib
-    h = hashlib.sha256()
-    csrc = os.path.join(ROOT, "radio-mapper_amd", "csrc")
-    for f in sorted(os.listdir(csrc)):
-        if f.endswith((".hip", ".hpp")):
-            h.update(f.encode())
-            h.update(open(os.path.join(csrc, f), "rb").read())
-    return h.hexdigest()[:16]
+    """sha256 over everything the library is built from (__graft_entry__.source_digest: kernel sources, include/rmx.h,
+    compiler flags).  The same value is compiled into the binary (rmx_build_info) and written beside every recorded
+    profiles/traffic_*.json / pmc_latest.json (tools/summarize_prof.py); bench.py refuses a figure, or a binary, whose
+    digest is not the current one."""
+    import __graft_entry__ as ge
+    return ge.source_digest()
 
 
 def recorded_traffic(config):
@@ -269,6 +268,30 @@ def recorded_counters(launch_ms):
     if c.get("TCC_HIT_sum") is not None and c.get("TCC_MISS_sum"):
         out["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
     return out
+
+
+VALU_CLOCK_GHZ = 2.4        # MI355X_MICROARCH.md: max clock; a wave64 VALU instruction occupies its 32-wide SIMD for 2 cycles
+N_SIMDS = 256 * 4
+
+
+def recorded_valu(launch_ms):
+    """`roofline.valu`: the fused kernel against the resource that actually binds it -- fp32 VALU issue.  Wave-instructions
+    per launch from profiles/pmc_latest.json (same digest rule as the traffic figure), their issue time at the data-sheet
+    rate of 2 cycles per wave64 instruction on each of the 1024 SIMDs at 2.4 GHz, and that time over this run's launch."""
+    pj = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    try:
+        d = json.load(open(pj))
+    except Exception:
+        return None
+    if d.get("source_digest") != source_digest():
+        return {"stale": f"profiles/pmc_latest.json (tag {d.get('tag')}) was recorded on other sources; re-run tools/profile.sh"}
+    n = d.get("counters", {}).get("SQ_INSTS_VALU")
+    if not n or not launch_ms:
+        return None
+    issue_ms = n * 2.0 / (N_SIMDS * VALU_CLOCK_GHZ * 1e9) * 1e3
+    return {"wave_instructions": n, "issue_ms_at_2cyc": issue_ms, "frac_of_launch": issue_ms / launch_ms,
+            "clock_ghz_assumed": VALU_CLOCK_GHZ, "simds": N_SIMDS,
+            "source": f"profiles/pmc_latest.json (tag {d.get('tag')}, SQ_INSTS_VALU per launch of {d.get('kernel')})"}
 
 
 class Shape:
@@ -380,7 +403,13 @@ def other_config(torch, xcorr, name, dev, dev_index, sync_all, cpu_thr):
     elapsed, region_ms = timed_steps(torch, sh, steps, sync_all)
     ms = elapsed * 1e3 / steps
     alg = sh.alg_bytes_per_step()
-    out = {"workload": cfg["what"], "steps": steps, "warmup": warm, "ms_per_step": ms,
+    # one more step with every launch bracketed by HIP events (not inside the timed region: two event records per launch
+    # are a tenth of cfg1's whole step): ms per kernel family of this shape
+    sh.eng.set_option("timing", 1)
+    sh.step()
+    by_kernel = sh.eng.last_timing_by_kernel()
+    sh.eng.set_option("timing", 0)
+    out = {"workload": cfg["what"], "steps": steps, "warmup": warm, "ms_per_step": ms, "kernel_ms": by_kernel,
            "value": sh.W * sh.P * sh.N * sh.D / (ms * 1e-3), "unit": "samples/s",
            "alg_bytes_per_step": alg,
            "roofline_frac": alg / (region_ms / steps * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -393,6 +422,44 @@ def other_config(torch, xcorr, name, dev, dev_index, sync_all, cpu_thr):
     sh.close()
     out["wall_s"] = time.perf_counter() - t_all
     return out
+
+
+PROJECTION_GPUS = (1, 2, 4, 8)
+
+
+def projection_table(ms_by_gpus, job_windows):
+    """{G: {windows_per_gpu, ms_per_step, efficiency_vs_G1}} from one GPU's ms per step on job_windows / G windows.  The path
+    has no collective (windows block-shard, host gather outside the timed region), so G GPUs finish the job when the
+    slowest finishes its block: time(G) = ms(job / G); strong-scaling efficiency = time(1) / (G * time(G))."""
+    t1 = ms_by_gpus[1]
+    return {str(g): {"windows_per_gpu": -(-job_windows // g), "ms_per_step": ms,
+                     "efficiency_vs_G1": t1 / (g * ms)} for g, ms in sorted(ms_by_gpus.items())}
+
+
+def strong_scaling_projection(torch, sh, sync_all, steps=40, warm=5):
+    """One GPU stands in for each rank of a G-GPU strong-scaling run of the headline job (no 8-GPU node is available to
+    this build): the first ceil(W / G) resident windows through the same device-pointer call, `steps` timed steps after
+    `warm` warm-up steps each, G = 1 first.  A PROJECTION: it contains the partial-round and launch-overhead cost of
+    small blocks (512 windows = two rounds of the persistent grid), not PCIe / host contention between real ranks."""
+    import time as _t
+    from radio_mapper_amd.shard import window_shard
+    ms = {}
+    for g in PROJECTION_GPUS:
+        _s, wg = window_shard(sh.W, 0, g)          # rank 0's block is the largest
+        if wg < 1:
+            continue
+        call = lambda: sh.eng.correlate_device(sh.x.data_ptr(), wg, sh.lag.data_ptr(), sh.frac.data_ptr(), sh.peak.data_ptr())
+        for _ in range(warm):
+            call()
+        sync_all()
+        t0 = _t.perf_counter()
+        for _ in range(steps):
+            call()
+        sync_all()
+        ms[g] = (_t.perf_counter() - t0) * 1e3 / steps
+    out = projection_table(ms, sh.W)
+    return {"kind": "projection from ONE GPU (no multi-GPU hardware was available): G GPUs = this GPU on ceil(W / G) windows",
+            "job_windows": sh.W, "steps": steps, "warmup": warm, "by_gpus": out}
 
 
 def job_shard(config, scaling, windows, rank, n_gpus):
@@ -431,9 +498,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the other four BASELINE shapes (profiling runs)")
     ap.add_argument("--no-single-group", action="store_true", help="skip the one-window latency probe (profiling runs)")
+    ap.add_argument("--no-projection", action="store_true", help="skip the one-GPU strong-scaling projection (profiling runs)")
     ap.add_argument("--no-host-path", action="store_true", help="skip the host-pointer legs (profiling runs)")
     ap.add_argument("--profile", action="store_true",
-                    help="the timed path and its parity only: --no-other-configs --no-single-group --no-host-path --no-cpu-baseline")
+                    help="the timed path and its parity only: --no-other-configs --no-projection --no-single-group --no-host-path --no-cpu-baseline")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU work for cpu_baseline")
     ap.add_argument("--launch-check", action="store_true",
                     help="rendezvous + shard + gather only (no compute, no metric): tests the N-rank launcher")
@@ -441,7 +509,7 @@ def main():
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
     if args.profile:
-        args.no_other_configs = args.no_single_group = args.no_host_path = args.no_cpu_baseline = True
+        args.no_other_configs = args.no_projection = args.no_single_group = args.no_host_path = args.no_cpu_baseline = True
 
     env_world = os.environ.get("WORLD_SIZE")
     if args.gpus > 1 and env_world is None:
@@ -510,6 +578,14 @@ def main():
         ge.build()
     if world > 1:
         barrier()
+    # which binary runs: the digest compiled into the loaded library against the digest of the sources in this tree
+    build_info = xcorr.build_info()
+    src_digest = source_digest()
+    if build_info.get("source_digest") != src_digest:
+        print(f"bench.py: {xcorr.library_path()} was built from other sources (binary digest "
+              f"{build_info.get('source_digest')} != source digest {src_digest}); rebuild with "
+              f"`python -c 'import __graft_entry__ as g; g.build(force=True)'`", file=sys.stderr)
+        sys.exit(3)
     dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
 
@@ -523,7 +599,6 @@ def main():
     sh = Shape(torch, xcorr, args.config, dev, dev_index, W, buoys=args.buoys, seed_offset=7919 * rank)
     B, N, P, D, fs, caf = sh.B, sh.N, sh.P, sh.D, sh.fs, sh.caf
     eng, x, lag, frac, peak = sh.eng, sh.x, sh.lag, sh.frac, sh.peak
-    eng.set_option("timing", 1)   # HIP events around every launch, on the launch stream
     step = sh.step
 
     def sync_all():
@@ -539,37 +614,60 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    region_order = []
+    # the other BASELINE shapes, same process, N = 1 only (they are parity-test cases, not the metric: bounded steps).
+    # They run BEFORE the headline region: whatever state they leave the device in is the state a service that handles
+    # several shapes is in, and the headline region below is then still exactly W warm-up + K timed steps.
+    others = None
+    if rank == 0 and n_gpus == 1 and args.config == "cfg3" and not args.no_other_configs:
+        others = {}
+        for name in ("cfg1", "cfg2", "cfg4", "cfg5"):
+            try:
+                others[name] = other_config(torch, xcorr, name, dev, dev_index, sync_all, cpu_threads())
+            except Exception as e:      # a shape that fails must not take the headline line with it
+                others[name] = {"error": f"{type(e).__name__}: {e}"}
+        region_order.append("other_configs (cfg1, cfg2, cfg4, cfg5: warm-up, timed steps, parity each)")
+    # one-GPU projection of the 1 -> 8 GPU strong-scaling curve: the path has no collective, so G GPUs on
+    # the config's job = one GPU on 1/G of its windows; timed on the resident windows of the headline shape
+    projection = None
+    if rank == 0 and n_gpus == 1 and args.config == "cfg3" and not args.no_projection and not caf:
+        projection = strong_scaling_projection(torch, sh, sync_all)
+        region_order.append("strong_scaling_projection (cfg3 on W/G windows, G = 1, 2, 4, 8)")
+
+    eng.set_option("timing", 1)   # HIP events around every launch, on the launch stream
     for _ in range(warm):
         step()
-    # (a) the driver's own contract and nothing else: W warm-up steps, then exactly K timed steps.  On a device that has
-    # just been idle this measures the clock ramp as well: reported as ms_per_step_cold.
-    cold_elapsed, _cold_region = timed_steps(torch, sh, steps, sync_all)
-    ms_per_step_cold = max_over_ranks(cold_elapsed) * 1e3 / steps
-    # (b) untimed pre-warm, then the same K steps again: the device needs some hundred milliseconds of load to settle
-    # on its sustained clock (the first timed steps after a short warm-up run 3-8 % slower per step than 3000 do);
-    # "prewarm_steps" counts everything that ran before the headline region beyond the W warm-up steps
+    # (a) HEADLINE: the driver's contract and nothing else -- W warm-up steps of this shape, then exactly K timed steps
+    # bracketed by barrier + synchronize; HIP events on the launch stream (the ctx uses torch's current stream) around
+    # the same region give the back-to-back launch duration of roofline.achieved
+    elapsed, region_ms = timed_steps(torch, sh, steps, sync_all)
+    elapsed = max_over_ranks(elapsed)
+    ms_per_step = elapsed * 1e3 / steps
+    region_order += [f"warmup ({warm} steps)", f"timed HEADLINE region ({steps} steps)"]
+    # (b) untimed pre-warm, then the same K steps again: a device that has just been idle needs some hundred
+    # milliseconds of load to settle on its sustained clock; "prewarm_steps" counts everything that ran between the
+    # headline region and the sustained one
     prewarm = 0
     if args.config == "cfg3":
         prewarm = max(0, int(os.environ.get("RMX_BENCH_PREWARM", "300")) - warm - steps)
     for _ in range(prewarm):
         step()
-    # HIP events on the launch stream (the ctx uses torch's current stream) around the timed region:
-    # the sustained, back-to-back launch duration (isolated launches run at a higher clock)
-    elapsed, region_ms = timed_steps(torch, sh, steps, sync_all)
-    prewarm += steps            # the cold region ran before the headline region too
+    sus_elapsed, sus_region_ms = timed_steps(torch, sh, steps, sync_all)
+    ms_per_step_sustained = max_over_ranks(sus_elapsed) * 1e3 / steps
+    region_order += [f"prewarm ({prewarm} steps)", f"timed sustained region ({steps} steps)"]
     # kernel durations from the HIP events bracketing every launch on the launch stream: the last
     # step of the timed region, then the same step repeated with a read-back after each
     fwd_ms = pair_ms = 0.0
     fwd_n = pair_n = 0
     n_meas = max(min(steps, 10 if not caf else 1), 1)
+    by_kernel = None
     for k in range(n_meas):
         if k > 0:
             step()
         tm = eng.last_timing()
         fwd_ms += tm["fwd_ms"]; fwd_n += tm["fwd_launches"]
         pair_ms += tm["pair_ms"]; pair_n += tm["pair_launches"]
-    elapsed = max_over_ranks(elapsed)
-    ms_per_step = elapsed * 1e3 / steps
+        by_kernel = eng.last_timing_by_kernel()
     seen = ranks_seen()
 
     # PCIe-inclusive rate of the same step through the host-pointer entry of the C ABI (reported, never `value`):
@@ -650,16 +748,6 @@ def main():
     headline_workload = cfg["what"]
     sh.close()
 
-    # the other BASELINE shapes, same process, N = 1 only (they are parity-test cases, not the metric: bounded steps)
-    others = None
-    if rank == 0 and n_gpus == 1 and args.config == "cfg3" and not args.no_other_configs:
-        others = {}
-        for name in ("cfg1", "cfg2", "cfg4", "cfg5"):
-            try:
-                others[name] = other_config(torch, xcorr, name, dev, dev_index, sync_all, cpu_threads())
-            except Exception as e:      # a shape that fails must not take the headline line with it
-                others[name] = {"error": f"{type(e).__name__}: {e}"}
-
     if rank == 0:
         units_per_step = W_total * P * N * D                  # IQ samples cross-correlated per step
         value = units_per_step / (ms_per_step * 1e-3)
@@ -667,6 +755,7 @@ def main():
             launches_per_step = max(pair_n / n_meas, 1.0)
             kernel = "k_win (fused forward + pair kernel), one launch per step"
             launch_ms = region_ms / (steps * launches_per_step)
+            launch_ms_sustained = sus_region_ms / (steps * launches_per_step)
             isolated_launch_ms = pair_ms / max(pair_n, 1)
         else:
             # multi-kernel paths: the figure is for the whole kernel sequence of one step (HIP events on the
@@ -678,6 +767,7 @@ def main():
                        "+ g_final" if B <= 4 and W >= 4 else
                        "four-step sequence g_cols_fwd + g_rows + g_rows(product, inverse) + g_cols_inv + g_final"))
             launch_ms = region_ms / steps
+            launch_ms_sustained = sus_region_ms / steps
             isolated_launch_ms = None
         alg_bytes_per_launch = alg_bytes_per_step_gpu / launches_per_step
         achieved = alg_bytes_per_launch / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
@@ -686,22 +776,32 @@ def main():
         line = {
             "metric": "IQ samples cross-correlated per second" + (" (pair-window-Doppler-bin samples)" if caf else ""),
             "value": value, "unit": "samples/s", "n_gpus": n_gpus, "ranks_seen": seen, "steps": steps,
-            "warmup": warm, "prewarm_steps": prewarm, "engine_calls": calls_headline, "ms_per_step": ms_per_step,
-            "ms_per_step_cold": ms_per_step_cold,
+            "warmup": warm, "engine_calls": calls_headline, "ms_per_step": ms_per_step,
+            "ms_per_step_sustained": ms_per_step_sustained, "prewarm_steps": prewarm,
+            "region_order": region_order,
+            "build": {"binary_digest": build_info.get("source_digest"), "source_digest": src_digest,
+                      "library": os.path.relpath(xcorr.library_path(), ROOT), "info": build_info.get("text")},
             "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": headline_workload, "name": args.config,
                        "n_buoys": B, "n_pairs": P, "n_samples": N, "windows_per_gpu": W, "channels": C,
                        "doppler_bins": D if caf else None,
                        "windows_total": W_total, "parallelism": f"windows sharded x{n_gpus}, no collective"},
-            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
+            # `bound` is the roofline north_star declares for the path and the one `frac` is taken against; `limiter` is the
+            # resource the counters say the dominant kernel actually waits on
+            "roofline": {"bound": "hbm", "limiter": "fp32-valu-issue" if fused else "hbm (two passes per transform) + CU-side issue",
+                         "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "alg_bytes_per_launch": alg_bytes_per_launch,
-                         "launch_ms": launch_ms, "isolated_launch_ms": isolated_launch_ms,
+                         "launch_ms": launch_ms, "launch_ms_sustained": launch_ms_sustained,
+                         "frac_sustained": alg_bytes_per_launch / (launch_ms_sustained * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "isolated_launch_ms": isolated_launch_ms,
+                         "kernel_ms_per_step": by_kernel,
                          "fwd_kernel_ms_per_step": fwd_ms / n_meas,
                          "pair_kernel_ms_per_step": pair_ms / n_meas,
                          "whole_path_frac": alg_bytes_per_step_gpu / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "whole_path_frac_cold": alg_bytes_per_step_gpu / (ms_per_step_cold * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "whole_path_frac_sustained": alg_bytes_per_step_gpu / (ms_per_step_sustained * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "valu": recorded_valu(launch_ms) if fused else None,
                          "counters": recorded_counters(launch_ms) if fused else None,
                          "fp32_valu_and_lds": "DESIGN.md section 7: the fused kernel is bound by fp32 VALU issue (70 % of the launch "
                                               "with DPP / compare forms weighted), not by HBM"},
@@ -712,6 +812,7 @@ def main():
             "host_path_u8_identical": host_u8_same,
             "device_u8_ms_per_step": dev_u8_ms,                 # raw uint8 I/Q resident in HBM (RMX_IN_U8 | RMX_IN_DEVICE)
             "single_group": single,
+            "strong_scaling_projection": projection,
             "other_configs": others,
             "cpu_baseline": cpu,
             "parity": parity,

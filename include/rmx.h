@@ -195,6 +195,18 @@ int rmx_synchronize(rmx_ctx* ctx);
 int rmx_last_timing(rmx_ctx* ctx, float* fwd_ms, int* fwd_launches, float* pair_ms,
                     int* pair_launches);
 
+/* The same per kernel family of EVERY path (N = 4096, whole-window, four-step, CAF): kind = 0, 1, 2, ... until the call
+ * returns RMX_E_INVAL; *name is a static string ("k_win|k_pair", "g_cols_fwd", "g_rows_fused", "g_rows_anchor",
+ * "g_cols_inv", "g_final", "g_win_*", ...), *ms the summed HIP-event time of that family's launches in the last
+ * rmx_xcorr_batch / rmx_caf_batch call, *launches their number.  Diagnostic only: no reference counterpart (the
+ * reference times nothing on this path); bench.py reports it per BASELINE shape.  Any pointer may be NULL. */
+int rmx_last_timing_kind(rmx_ctx* ctx, int kind, const char** name, float* ms, int* launches);
+
+/* Static text naming what this binary was built from: "RMX_BUILD_INFO source_digest=<16 hex> arch=gfx950", the digest
+ * being sha256 over the kernel sources, this header and the compiler flags as __graft_entry__.source_digest() computes
+ * it.  bench.py prints it beside the digest of the sources it sees and refuses to run on a mismatch; never fails. */
+const char* rmx_build_info(void);
+
 /* Bytes of device scratch the ctx holds (spectra, tables, staging). */
 size_t rmx_scratch_bytes(const rmx_ctx* ctx);
 

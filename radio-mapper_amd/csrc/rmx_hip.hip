@@ -787,6 +787,50 @@ static int ensure_events(rmx_ctx* c, size_t n) {
     return RMX_OK;
 }
 
+// Per-launch timing (option "timing"): every kernel launch of a call is bracketed by two HIP events on the launch stream
+// and tagged with its kernel family; rmx_last_timing / rmx_last_timing_kind read them back.  The event pool grows in
+// front of every record (a budget computed ahead of the chunk loop was too small once every chunk could take
+// the partial-round route), so no call pattern can index past it.
+enum TimeKind {
+    kTkFwd4096 = 0,      // k_fwd
+    kTkPair4096 = 1,     // k_win (fused forward + pairs) or k_pair_res / k_pair_str
+    kTkColsFwd = 2,      // g_cols_fwd
+    kTkRowsFwd = 3,      // g_rows (forward)
+    kTkRowsFused = 4,    // g_rows_fused (forward rows, products, inverse rows)
+    kTkRowsAnchor = 5,   // g_rows_anchor
+    kTkRowsInv = 6,      // g_rows (product, inverse)
+    kTkColsInv = 7,      // g_cols_inv
+    kTkFinal = 8,        // g_final
+    kTkWindow = 9,       // g_win_fused / g_win_scr / g_win_scr14 / g_win_eo15: whole windows in one kernel
+    kTkFwdSmall = 10,    // g_fwd_small
+    kTkPairSmall = 11,   // g_pair_small
+    kTkCafSelect = 12,   // k_caf_select / k_caf_select_all
+    kTkCount = 13
+};
+static const char* const kTimeKindName[kTkCount] = {
+    "k_fwd", "k_win|k_pair", "g_cols_fwd", "g_rows_fwd", "g_rows_fused", "g_rows_anchor", "g_rows_inv", "g_cols_inv",
+    "g_final", "g_win_*", "g_fwd_small", "g_pair_small", "k_caf_select"};
+static int tm_begin(rmx_ctx* c) {
+    if (!c->timing) return RMX_OK;
+    const int rc = ensure_events(c, c->ev_used + 2);
+    if (rc != RMX_OK) return rc;
+    RMX_HIP(c, hipEventRecord(c->ev[c->ev_used], c->stream));
+    return RMX_OK;
+}
+static int tm_end(rmx_ctx* c, int kind) {
+    if (!c->timing) return RMX_OK;
+    RMX_HIP(c, hipEventRecord(c->ev[c->ev_used + 1], c->stream));
+    c->ev_used += 2;
+    c->ev_kind.push_back(kind);
+    return RMX_OK;
+}
+static void tm_reset(rmx_ctx* c) {
+    c->ev_used = 0;
+    c->ev_kind.clear();
+}
+#define RMX_TM_BEGIN(c) do { const int rc_tm_ = tm_begin(c); if (rc_tm_ != RMX_OK) return rc_tm_; } while (0)
+#define RMX_TM_END(c, kind) do { const int rc_tm_ = tm_end((c), (kind)); if (rc_tm_ != RMX_OK) return rc_tm_; } while (0)
+
 // pair plan (host_plan.hpp: validation, anchor runs, parts of <= pairs_per_block consecutive items) -> device copies
 static int build_plan(rmx_ctx* c, const int32_t* pairs, int n_pairs) {
     host::PairPlan pp;
@@ -1205,6 +1249,7 @@ static int generic_forward(rmx_ctx* c, const void* d_iq, int w0, int wc, bool u8
     float2* dst = rot ? c->g_spec_r : c->g_spec;
     if (L <= kGenSmallMaxL) {
         const int sthr = gen_small_threads(L);
+        RMX_TM_BEGIN(c);
         if (u8)
             hipLaunchKernelGGL(g_fwd_small<true>, dim3(items), dim3(sthr), (size_t)gen::lp(L) * 8, st, d_iq, dst, c->g_tw, N, logL,
                                first_item, fwd_scale, rot);
@@ -1212,6 +1257,7 @@ static int generic_forward(rmx_ctx* c, const void* d_iq, int w0, int wc, bool u8
             hipLaunchKernelGGL(g_fwd_small<false>, dim3(items), dim3(sthr), (size_t)gen::lp(L) * 8, st, d_iq, dst, c->g_tw, N, logL,
                                first_item, fwd_scale, rot);
         RMX_HIP(c, hipGetLastError());
+        RMX_TM_END(c, kTkFwdSmall);
         return RMX_OK;
     }
     const int l1 = c->g_logL1, l2 = c->g_logL2, L1 = 1 << l1, L2 = 1 << l2;
@@ -1226,7 +1272,9 @@ static int generic_forward(rmx_ctx* c, const void* d_iq, int w0, int wc, bool u8
         int a_l1 = l1, a_l2 = l2, a_lo = c->g_lo_bits;
         long a_first = first_item;
         void* args[] = {&a_iq, &a_out, &a_tw, &a_l1, &a_l2, &a_first, &a_lo, &a_thi, &a_tlo, &a_rot};
+        RMX_TM_BEGIN(c);
         RMX_HIP(c, hipLaunchKernel(c->g_cols_fwd_fn[u8 ? 1 : 0], dim3(ntiles, items), dim3(cthr), args, clds, st));
+        RMX_TM_END(c, kTkColsFwd);
     }
     if (cols_only) {                      // g_rows_fused does the rows
         RMX_HIP(c, hipGetLastError());
@@ -1243,7 +1291,9 @@ static int generic_forward(rmx_ctx* c, const void* d_iq, int w0, int wc, bool u8
         float a_scale = fwd_scale;
         void* args[] = {&a_data, &a_tw, &a_l2, &a_L1, &a_l1, &a_L, &a_lo, &a_thi, &a_tlo, &a_scale, &a_rows, &a_null, &a_null,
                         &a_pairs, &a_zero, &a_zero, &a_tpr};
+        RMX_TM_BEGIN(c);
         RMX_HIP(c, hipLaunchKernel(c->g_rows_fwd_fn, dim3((unsigned)((rows + rpw - 1) / rpw)), dim3(kGThreads), args, rlds, st));
+        RMX_TM_END(c, kTkRowsFwd);
     }
     RMX_HIP(c, hipGetLastError());
     return RMX_OK;
@@ -1263,9 +1313,11 @@ static int generic_pairs(rmx_ctx* c, int w0, int wc, int n_pairs, int* d_lag, fl
     const float2* spec_j = use_rot ? c->g_spec_r : c->g_spec;
     if (L <= kGenSmallMaxL) {
         const int sthr = gen_small_threads(L);
+        RMX_TM_BEGIN(c);
         hipLaunchKernelGGL(g_pair_small, dim3(slots), dim3(sthr), (size_t)gen::lp(L) * 8 + (size_t)sthr * 8, st, c->g_spec,
                            spec_j, c->g_tw, c->g_pairs, n_pairs, B, N, logL, (long)w0, out_scale, d_lag, d_frac, d_peak);
         RMX_HIP(c, hipGetLastError());
+        RMX_TM_END(c, kTkPairSmall);
         return RMX_OK;
     }
     const int l1 = c->g_logL1, l2 = c->g_logL2, L1 = 1 << l1, L2 = 1 << l2;
@@ -1291,8 +1343,10 @@ static int generic_pairs(rmx_ctx* c, int w0, int wc, int n_pairs, int* d_lag, fl
         long a_L = L, a_units = units;
         float a_scale = fs * fs;
         void* args[] = {&colsp, &prodp, &twp, &a_L1, &a_l1, &a_L, &a_lo, &thip, &tlop, &a_scale, &a_units, &pp, &a_np};
+        RMX_TM_BEGIN(c);
         RMX_HIP(c, hipLaunchKernel(def_plan ? c->g_fused_def_fn : c->g_fused_fn, grid, dim3(kGThreads), args,
                                    gen_fused_lds(L2, def_plan && gen::fused_tw_regs(B, l2, true)), st));
+        RMX_TM_END(c, kTkRowsFused);
     } else if (c->g_rows_anchor_fn && c->plan_all_pairs && n_pairs == B * (B - 1) / 2 && B >= c->g_rows_anchor_min_b) {
         // default pair list: the anchor's row stays in registers over its run of pairs (from 6 buoys on: with 5 the runs are
         // too short for the per-workgroup set-up, 0.649 -> 0.692 ms at N = 16384; with 6 / 7 / 8 buoys 0.89 -> 0.84, 1.16 -> 1.10,
@@ -1303,7 +1357,9 @@ static int generic_pairs(rmx_ctx* c, int w0, int wc, int n_pairs, int* d_lag, fl
         long a_L = L;
         float a_scale = 1.0f;
         void* args[] = {&a_data, &a_tw, &a_L1, &a_l1, &a_L, &a_lo, &a_thi, &a_tlo, &a_scale, &a_spec, &a_specj, &a_np, &a_B};
+        RMX_TM_BEGIN(c);
         RMX_HIP(c, hipLaunchKernel(c->g_rows_anchor_fn, dim3((unsigned)((L1 / rpw) * (B - 1)), (unsigned)wc), dim3(kGThreads), args, rlds, st));
+        RMX_TM_END(c, kTkRowsAnchor);
     } else
     {
         float2* a_data = c->g_prod;
@@ -1314,7 +1370,9 @@ static int generic_pairs(rmx_ctx* c, int w0, int wc, int n_pairs, int* d_lag, fl
         float a_scale = 1.0f;
         void* args[] = {&a_data, &a_tw, &a_l2, &a_L1, &a_l1, &a_L, &a_lo, &a_thi, &a_tlo, &a_scale, &a_rows, &a_spec, &a_specj,
                         &a_pairs, &a_np, &a_B, &a_tpr};
+        RMX_TM_BEGIN(c);
         RMX_HIP(c, hipLaunchKernel(c->g_rows_inv_fn, dim3((unsigned)((rows + rpw - 1) / rpw)), dim3(kGThreads), args, rlds, st));
+        RMX_TM_END(c, kTkRowsInv);
     }
     {
         const float2 *a_in = c->g_prod, *a_tw = c->g_tw1;
@@ -1322,11 +1380,15 @@ static int generic_pairs(rmx_ctx* c, int w0, int wc, int n_pairs, int* d_lag, fl
         GTile* a_rec = c->g_rec;
         float* a_halo = c->g_halo;
         void* args[] = {&a_in, &a_tw, &a_l1, &a_l2, &a_rec, &a_halo};
+        RMX_TM_BEGIN(c);
         RMX_HIP(c, hipLaunchKernel(c->g_cols_inv_fn, dim3(ntiles, slots), dim3(cthr), args, clds, st));
+        RMX_TM_END(c, kTkColsInv);
     }
+    RMX_TM_BEGIN(c);
     hipLaunchKernelGGL(g_final, dim3(slots), dim3(64), 0, st, N, l1, l2, lt, c->g_rec, c->g_halo, ntiles, slots,
                        (long)w0 * n_pairs, out_scale, d_lag, d_frac, d_peak);
     RMX_HIP(c, hipGetLastError());
+    RMX_TM_END(c, kTkFinal);
     return RMX_OK;
 }
 
@@ -1359,6 +1421,7 @@ static int generic_batch(rmx_ctx* c, const void* d_iq, int n_windows, int n_pair
             const float out_scale = std::ldexp(1.0f, 3 * kTw1ScaleLog2 - 14);
             const k8::Pair2* prs = def_list ? nullptr : reinterpret_cast<const k8::Pair2*>(c->g_pairs);
             const int stag = (int)c->knobs.get_or("stag", 1);
+            RMX_TM_BEGIN(c);
             if (u8)
                 hipLaunchKernelGGL(k8::k_win8k<true>, dim3((unsigned)grid), dim3(kThreads), k8::kLds8Bytes, c->stream, d_iq,
                                    c->g_ws_scratch, c->g_k8_tw1, c->g_k8_tw2, c->n_buoys, prs, n_pairs, 0L, out_scale, d_lag,
@@ -1368,17 +1431,22 @@ static int generic_batch(rmx_ctx* c, const void* d_iq, int n_windows, int n_pair
                                    c->g_ws_scratch, c->g_k8_tw1, c->g_k8_tw2, c->n_buoys, prs, n_pairs, 0L, out_scale, d_lag,
                                    d_frac, d_peak, n_windows, stag);
             RMX_HIP(c, hipGetLastError());
+            RMX_TM_END(c, kTkWindow);
             return RMX_OK;
         }
 #endif
         if (logL == 15) {                          // g_win_eo15: one more table
             const float2* a_twl = c->g_tw_l;
             void* args[] = {&a_iq, &a_scr, &a_tw, &a_twl, &a_nb, &a_nw, &a_first, &a_fs, &a_os, &a_pairs, &a_np, &d_lag, &d_frac, &d_peak};
+            RMX_TM_BEGIN(c);
             RMX_HIP(c, hipLaunchKernel(c->g_ws_fn[u8 ? 1 : 0], dim3((unsigned)grid), dim3(c->g_ws_thr), args, c->g_ws_lds, c->stream));
+            RMX_TM_END(c, kTkWindow);
             return RMX_OK;
         }
         void* args[] = {&a_iq, &a_scr, &a_tw, &a_nb, &a_nw, &a_first, &a_fs, &a_os, &a_pairs, &a_np, &d_lag, &d_frac, &d_peak};
+        RMX_TM_BEGIN(c);
         RMX_HIP(c, hipLaunchKernel(c->g_ws_fn[u8 ? 1 : 0], dim3((unsigned)grid), dim3(c->g_ws_thr), args, c->g_ws_lds, c->stream));
+        RMX_TM_END(c, kTkWindow);
         return RMX_OK;
     }
     if (c->g_wfused) {
@@ -1393,8 +1461,10 @@ static int generic_batch(rmx_ctx* c, const void* d_iq, int n_windows, int n_pair
         const GPair* a_pairs = c->g_pairs;
         int a_np = n_pairs;
         void* args[] = {&a_iq, &a_tw, &a_nw, &a_first, &a_fs, &a_os, &a_pairs, &a_np, &d_lag, &d_frac, &d_peak};
+        RMX_TM_BEGIN(c);
         RMX_HIP(c, hipLaunchKernel(c->g_wf_fn[def_plan ? 1 : 0][u8 ? 1 : 0], dim3((unsigned)((n_windows + upw - 1) / upw)),
                                    dim3(kGThreads), args, c->g_wf_lds[def_plan ? 1 : 0], c->stream));
+        RMX_TM_END(c, kTkWindow);
         return RMX_OK;
     }
     for (int w0 = 0; w0 < n_windows; w0 += c->g_chunk) {
@@ -1675,7 +1745,7 @@ static int fwd4096(rmx_ctx* c, const void* d_iq, int w0, int wc, bool u8, const 
         }
     }
     float4* dst = rot ? c->d_spec_r : c->d_spec;
-    if (c->timing) RMX_HIP(c, hipEventRecord(c->ev[c->ev_used], c->stream));
+    RMX_TM_BEGIN(c);
     if (u8)
         hipLaunchKernelGGL(k_fwd<true>, dim3(n_items), dim3(kThreads), kLdsBytes, c->stream, d_iq, dst, c->d_tw1, c->d_tw2,
                            first_item, 1.0f, rot, wrap);
@@ -1683,11 +1753,7 @@ static int fwd4096(rmx_ctx* c, const void* d_iq, int w0, int wc, bool u8, const 
         hipLaunchKernelGGL(k_fwd<false>, dim3(n_items), dim3(kThreads), kLdsBytes, c->stream, d_iq, dst, c->d_tw1, c->d_tw2,
                            first_item, 1.0f, rot, wrap);
     RMX_HIP(c, hipGetLastError());
-    if (c->timing) {
-        RMX_HIP(c, hipEventRecord(c->ev[c->ev_used + 1], c->stream));
-        c->ev_used += 2;
-        c->ev_kind.push_back(0);
-    }
+    RMX_TM_END(c, kTkFwd4096);
     return RMX_OK;
 }
 static int pairs4096(rmx_ctx* c, int w0, int wc, int n_pairs, int* d_lag, float* d_frac, float* d_peak, float out_scale,
@@ -1697,7 +1763,7 @@ static int pairs4096(rmx_ctx* c, int w0, int wc, int n_pairs, int* d_lag, float*
     wc *= n_bins;
     const int xcd_map = (wc % 8 == 0) ? 1 : 0;
     const float4* spec_j = use_rot ? c->d_spec_r : c->d_spec;
-    if (c->timing) RMX_HIP(c, hipEventRecord(c->ev[c->ev_used], c->stream));
+    RMX_TM_BEGIN(c);
     if (c->resident)
         hipLaunchKernelGGL(k_pair_res, dim3(wc * n_parts), dim3(kThreads), kLdsResBytes, c->stream, (const float4*)c->d_spec,
                            spec_j, c->d_tw1, c->d_tw2, c->d_items, c->d_part_begin, n_parts, c->n_buoys, n_pairs, xcd_map,
@@ -1707,11 +1773,7 @@ static int pairs4096(rmx_ctx* c, int w0, int wc, int n_pairs, int* d_lag, float*
                            c->d_tw1, c->d_tw2, c->d_items, c->d_part_begin, n_parts, c->n_buoys, n_pairs, xcd_map, (long)w0,
                            out_scale, d_lag, d_frac, d_peak, i_wrap);
     RMX_HIP(c, hipGetLastError());
-    if (c->timing) {
-        RMX_HIP(c, hipEventRecord(c->ev[c->ev_used + 1], c->stream));
-        c->ev_used += 2;
-        c->ev_kind.push_back(1);
-    }
+    RMX_TM_END(c, kTkPair4096);
     return RMX_OK;
 }
 static float out_scale4096() {
@@ -1786,6 +1848,7 @@ int rmx_xcorr_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pa
     if (n_pairs < 0) return fail(c, RMX_E_INVAL, "n_pairs %d < 0", n_pairs);
     if (n_windows == 0 || n_pairs == 0) return RMX_OK;
     RMX_HIP(c, hipSetDevice(c->device));
+    tm_reset(c);
     // Few windows of N = 4096: the fused kernel is one workgroup per WINDOW -- (B + P) transforms in sequence, 92 us for
     // one window of 8 buoys, 344 us for 16 buoys, whatever the rest of the chip does -- while the per-transform kernels
     // spread a window's spectra and pairs over the CUs: 13-15 us for the same single windows (tools/exp_small4096.py;
@@ -1806,9 +1869,11 @@ int rmx_xcorr_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pa
     // (300 windows of 8 buoys: two rounds, 184 us); when the model says the r windows are cheaper through the
     // per-transform kernels than a round of the fused one, they go there (after the k full rounds, on the same stream).
     // The decision is taken per CHUNK of windows (a batch-wide tail larger than the last chunk ran past the
-    // chunk and past the spectrum scratch): chunk_tail(w0, wc) below is the chunk's own partial round, wc mod CUs, so it
-    // never exceeds the chunk, and the scratch of min(chunk, CUs) window slots covers it.  `tail` here only says that
-    // some chunk may take that route, and sizes the pair workgroups for the batch's last partial round.
+    // chunk and past the spectrum scratch): in the chunk loop below a chunk's own partial round, wc mod CUs, takes that
+    // route when the model says so for ITS size, so it never exceeds the chunk, and the scratch of min(chunk, CUs) window
+    // slots covers it.  `tail` here is the gate -- the largest remainder of ANY chunk that pays (every chunk but the last
+    // has chunk_windows windows; ADVICE r04: it used to look at the last chunk only) -- and sizes the pair workgroups
+    // (one plan per call) for that largest partial round.
     int tail = 0;
     const bool tail_ok = !small && !c->generic && c->fused && c->small_batch && c->n_buoys >= 3 && n_pairs == all_pairs &&
                          c->n_cus > 0 && (in_dev || n_windows <= kHostSubChunk);
@@ -1818,11 +1883,15 @@ int rmx_xcorr_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pa
     if (tail_ok && n_windows > c->n_cus) {
         const long cw = c->chunk_windows;
         const int last_wc = (int)(n_windows - ((long)(n_windows - 1) / cw) * cw);   // windows of the last chunk
-        const int r = last_wc % c->n_cus;
-        int q = 7;
-        if (r != 0 && tail_pays(r, &q)) {
-            tail = r;
-            ppb_small = q;
+        const int r_last = last_wc % c->n_cus;
+        const int r_full = (n_windows > cw) ? (int)(cw % c->n_cus) : 0;             // every earlier chunk's remainder
+        for (int r : {r_full > r_last ? r_full : r_last, r_full > r_last ? r_last : r_full}) {
+            int q = 7;
+            if (r != 0 && tail_pays(r, &q)) {
+                tail = r;
+                ppb_small = q;
+                break;
+            }
         }
     }
     if (!c->generic && !c->ppb_user) {
@@ -1893,14 +1962,6 @@ int rmx_xcorr_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pa
         rc = ensure_spec(c, fused_path ? (chunk_w < c->n_cus ? chunk_w : c->n_cus) : chunk_w);
         if (rc != RMX_OK) return rc;
     }
-    const int n_chunks = (n_windows + c->chunk_windows - 1) / c->chunk_windows;
-    c->ev_used = 0;
-    c->ev_kind.clear();
-    if (c->timing) {
-        const size_t subs = pipelined ? (size_t)(n_windows + kHostSubChunk - 1) / kHostSubChunk + n_chunks : n_chunks;
-        rc = ensure_events(c, subs * 4 + 8);
-        if (rc != RMX_OK) return rc;
-    }
     int n_sub = 0;
     for (int w0 = 0; w0 < n_windows; w0 += c->chunk_windows) {
         const int wc = (n_windows - w0 < c->chunk_windows) ? n_windows - w0 : c->chunk_windows;
@@ -1930,7 +1991,7 @@ int rmx_xcorr_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pa
                 }
                 // one persistent workgroup per CU (the kernel's LDS footprint allows exactly one)
                 const int wgrid = sc < c->n_cus ? sc : c->n_cus;
-                if (c->timing) RMX_HIP(c, hipEventRecord(c->ev[c->ev_used], c->stream));
+                RMX_TM_BEGIN(c);
 #ifdef RMX_EXPERIMENTS
                 if (c->win8) {
                     if (u8)
@@ -1959,11 +2020,7 @@ int rmx_xcorr_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pa
                                        c->d_tw1, c->d_tw2, c->n_buoys, wfirst, out_scale, d_lag, d_frac,
                                        d_peak, sc, c->dbg, c->stag);
                 RMX_HIP(c, hipGetLastError());
-                if (c->timing) {
-                    RMX_HIP(c, hipEventRecord(c->ev[c->ev_used + 1], c->stream));
-                    c->ev_used += 2;
-                    c->ev_kind.push_back(1);
-                }
+                RMX_TM_END(c, kTkPair4096);
             }
             if (wtail) {
                 rc = fwd4096(c, d_iq, w0 + wf, wtail, u8, nullptr);
@@ -2065,28 +2122,29 @@ int rmx_caf_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pair
     // Per chunk of windows: the un-rotated spectra once, then per hypothesis the de-rotated spectra (the rotation
     // is applied as the window is loaded), the pair kernels with X_i un-rotated and X_j de-rotated, and the
     // running d-major first maximum.  No augmented copy of the windows, no second engine.
-    const bool timing = c->timing;
-    c->timing = false;                    // (per-launch events are sized for rmx_xcorr_batch)
+    tm_reset(c);
     int chunk;
     if (c->generic) {
         rc = rmx::generic_ensure(c, n_pairs);
-        if (rc != RMX_OK) { c->timing = timing; return rc; }
+        if (rc != RMX_OK) return rc;
         chunk = c->g_chunk;
     } else {
         chunk = c->chunk_windows;
         rc = ensure_spec(c, n_windows < chunk ? n_windows : chunk);
-        if (rc != RMX_OK) { c->timing = timing; return rc; }
+        if (rc != RMX_OK) return rc;
     }
     const float osc = out_scale4096();
     if (batch_bins) {
         rc = fwd4096(c, d_iq, 0, n_windows, u8, nullptr);
         if (rc == RMX_OK) rc = fwd4096(c, d_iq, 0, n_windows, u8, c->caf_rot, n_dopplers);
         if (rc == RMX_OK) rc = pairs4096(c, 0, n_windows, n_pairs, c->caf_lag, c->caf_frac, c->caf_peak, osc, true, n_dopplers);
+        if (rc == RMX_OK) rc = tm_begin(c);
         if (rc == RMX_OK) {
             hipLaunchKernelGGL(k_caf_select_all, dim3((unsigned)((out_elems + 255) / 256)), dim3(256), 0, c->stream, n_dopplers,
                                (long)out_elems, c->caf_lag, c->caf_frac, c->caf_peak, b_dop, b_lag, b_frac, b_peak);
             if (hipGetLastError() != hipSuccess) rc = fail(c, RMX_E_HIP, "k_caf_select_all launch failed");
         }
+        if (rc == RMX_OK) rc = tm_end(c, kTkCafSelect);
     }
     for (int w0 = 0; !batch_bins && w0 < n_windows && rc == RMX_OK; w0 += chunk) {
         const int wc = n_windows - w0 < chunk ? n_windows - w0 : chunk;
@@ -2099,12 +2157,14 @@ int rmx_caf_batch(rmx_ctx* c, const void* iq, int n_windows, const int32_t* pair
                             : pairs4096(c, w0, wc, n_pairs, c->caf_lag, c->caf_frac, c->caf_peak, osc, true);
             if (rc != RMX_OK) break;
             const long first = (long)w0 * n_pairs, cnt = (long)wc * n_pairs;
+            rc = tm_begin(c);
+            if (rc != RMX_OK) break;
             hipLaunchKernelGGL(k_caf_select, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, c->stream, d, first, cnt,
                                c->caf_lag, c->caf_frac, c->caf_peak, b_dop, b_lag, b_frac, b_peak);
             if (hipGetLastError() != hipSuccess) rc = fail(c, RMX_E_HIP, "k_caf_select launch failed");
+            if (rc == RMX_OK) rc = tm_end(c, kTkCafSelect);
         }
     }
-    c->timing = timing;
     if (rc != RMX_OK) return rc;
     if (!out_dev) return fetch_out(c, out_elems, lag_int, lag_frac, peak, dop_idx);
     return RMX_OK;
@@ -2292,7 +2352,8 @@ int rmx_last_timing(rmx_ctx* c, float* fwd_ms, int* fwd_launches, float* pair_ms
     for (size_t k = 0; k < c->ev_kind.size(); ++k) {
         float ms = 0;
         RMX_HIP(c, hipEventElapsedTime(&ms, c->ev[2 * k], c->ev[2 * k + 1]));
-        if (c->ev_kind[k] == 0) { tf += ms; ++nf; } else { tp += ms; ++np; }
+        if (c->ev_kind[k] == rmx::kTkFwd4096) { tf += ms; ++nf; }
+        else if (c->ev_kind[k] == rmx::kTkPair4096) { tp += ms; ++np; }
     }
     if (fwd_ms) *fwd_ms = tf;
     if (fwd_launches) *fwd_launches = nf;
@@ -2300,6 +2361,32 @@ int rmx_last_timing(rmx_ctx* c, float* fwd_ms, int* fwd_launches, float* pair_ms
     if (pair_launches) *pair_launches = np;
     return RMX_OK;
 }
+
+int rmx_last_timing_kind(rmx_ctx* c, int kind, const char** name, float* ms, int* launches) {
+    if (!c) return RMX_E_INVAL;
+    if (kind < 0 || kind >= rmx::kTkCount) return RMX_E_INVAL;   // (no error text: callers enumerate kinds until this)
+    RMX_HIP(c, hipSetDevice(c->device));
+    RMX_HIP(c, hipStreamSynchronize(c->stream));
+    float t = 0;
+    int n = 0;
+    for (size_t k = 0; k < c->ev_kind.size(); ++k) {
+        if (c->ev_kind[k] != kind) continue;
+        float one = 0;
+        RMX_HIP(c, hipEventElapsedTime(&one, c->ev[2 * k], c->ev[2 * k + 1]));
+        t += one;
+        ++n;
+    }
+    if (name) *name = rmx::kTimeKindName[kind];
+    if (ms) *ms = t;
+    if (launches) *launches = n;
+    return RMX_OK;
+}
+
+#ifndef RMX_SOURCE_DIGEST
+#define RMX_SOURCE_DIGEST "unknown"
+#endif
+// (the marker in front of the digest lets __graft_entry__._stale() read it out of the file without loading the library)
+const char* rmx_build_info(void) { return "RMX_BUILD_INFO source_digest=" RMX_SOURCE_DIGEST " arch=gfx950"; }
 
 size_t rmx_scratch_bytes(const rmx_ctx* c) { return c ? c->scratch_bytes : 0; }
 

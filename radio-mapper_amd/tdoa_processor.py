@@ -141,13 +141,16 @@ class TDoACalculator:
     SPEED_OF_LIGHT = _C  # tdoa_processor.py:141
     MAX_ENGINES = 4      # engines kept alive (one rmx_ctx each: device scratch), least recently used evicted
 
-    def __init__(self, device: int = 0, devices: Optional[Sequence[int]] = None):
+    def __init__(self, device: int = 0, devices: Optional[Sequence[int]] = None, min_cut_samples: int = 128):
         """device: the GPU of a single-device calculator (the default).  devices: a list of GPUs, or "all" for every
         visible one -- with more than one entry a batch of windows / frequency groups is block-sharded over them by
-        `multi.MultiXcorrEngine` (one rmx_ctx and one host thread per device, no collective)."""
+        `multi.MultiXcorrEngine` (one rmx_ctx and one host thread per device, no collective).  min_cut_samples: the
+        shortest window a group may be CUT to when its windows differ in length (see _group_windows); 128 is the
+        shortest cut the reference's own clipping can produce."""
         self.logger = logging.getLogger(__name__ + ".TDoACalculator")
         self.device = device
         self.devices = devices
+        self.min_cut_samples = int(min_cut_samples)
         self._engines: Dict[Tuple[int, int], Any] = {}   # insertion order = recency
         self._tconf: Dict[Tuple[int, int], float] = {}
 
@@ -242,8 +245,13 @@ class TDoACalculator:
         # Windows that differ in length, or whose length is not a power of two: the reference clips an excerpt at the
         # end of the capture buffer (iq_stream_client.py:306-313: start = max(0, peak - 128), end = min(len, start + 256)),
         # so a peak in the last 128 bins gives e.g. 130 samples beside the other buoys' 256.  Every window keeps its
-        # START (that is what its time tag dates), so the group is cut to the largest power of two that every window
-        # holds -- the engine's window lengths -- instead of being dropped.
+        # START -- under this build's extension the time tag of a detection that carries IQ dates its window's first
+        # sample (SignalDetection above; the reference's own tag is time.time_ns() at detection time,
+        # iq_stream_client.py:221, and dates no sample) -- so the group is cut to the largest power of two that every
+        # window holds -- the engine's window lengths -- instead of being dropped.  The reference's clipping
+        # never leaves fewer than 129 samples, so a cut below min_cut_samples (128) is not one of its excerpts: such a
+        # group is refused rather than correlated on a noise-dominated stub.  Windows of one equal
+        # power-of-two length >= 16 are the caller's own choice and are not cut.
         per = 2 if iqs[0].dtype == np.uint8 else 1          # uint8: interleaved I, Q
         nmin = min(a.shape[0] // per for a in iqs)
         n = 1 << (max(nmin, 1).bit_length() - 1)
@@ -251,6 +259,10 @@ class TDoACalculator:
             self.logger.error(f"IQ windows of the group are too short to correlate ({nmin} samples); no TDoA measurements for it")
             return False, None
         if any(a.shape[0] != n * per for a in iqs):
+            if n < self.min_cut_samples:
+                self.logger.error(f"IQ windows of the group hold {sorted({a.shape[0] // per for a in iqs})} samples: their "
+                                  f"common cut of {n} is below {self.min_cut_samples}; no TDoA measurements for it")
+                return False, None
             self.logger.warning(f"IQ windows of the group hold {sorted({a.shape[0] // per for a in iqs})} samples; "
                                 f"correlating their first {n}")
             iqs = [a[:n * per] for a in iqs]

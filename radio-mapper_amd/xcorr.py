@@ -78,6 +78,10 @@ def load_library():
     lib.rmx_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(ci), C.POINTER(C.c_float),
                                     C.POINTER(ci)]
     lib.rmx_last_timing.restype = ci
+    lib.rmx_last_timing_kind.argtypes = [vp, ci, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(ci)]
+    lib.rmx_last_timing_kind.restype = ci
+    lib.rmx_build_info.argtypes = []
+    lib.rmx_build_info.restype = C.c_char_p
     lib.rmx_scratch_bytes.argtypes = [vp]
     lib.rmx_scratch_bytes.restype = C.c_size_t
     _lib = lib
@@ -86,7 +90,17 @@ def load_library():
 
 EXPORTS = ["rmx_version", "rmx_device_count", "rmx_create", "rmx_destroy", "rmx_last_error",
            "rmx_set_stream", "rmx_set_option", "rmx_set_default_option", "rmx_clear_default_options", "rmx_xcorr_batch", "rmx_caf_batch", "rmx_solve_batch", "rmx_detect_batch", "rmx_synchronize",
-           "rmx_last_timing", "rmx_scratch_bytes"]
+           "rmx_last_timing", "rmx_last_timing_kind", "rmx_build_info", "rmx_scratch_bytes"]
+
+
+def build_info() -> dict:
+    """rmx_build_info() parsed: {"source_digest": ..., "arch": ...} of the loaded binary."""
+    txt = load_library().rmx_build_info().decode()
+    out = {"text": txt}
+    for tok in txt.split()[1:]:
+        k, _, v = tok.partition("=")
+        out[k] = v
+    return out
 
 
 def set_default_option(key: str, value: int) -> None:
@@ -188,6 +202,20 @@ class XcorrEngine:
         nf, npair = C.c_int(), C.c_int()
         self._check(self._lib.rmx_last_timing(self._ctx, C.byref(f), C.byref(nf), C.byref(p), C.byref(npair)))
         return dict(fwd_ms=f.value, fwd_launches=nf.value, pair_ms=p.value, pair_launches=npair.value)
+
+    def last_timing_by_kernel(self) -> dict:
+        """{kernel family: {"ms": summed HIP-event time, "launches": n}} of the last correlate / caf call (option
+        "timing" = 1), families without a launch left out (rmx_last_timing_kind)."""
+        out = {}
+        kind = 0
+        while True:
+            name, ms, n = C.c_char_p(), C.c_float(), C.c_int()
+            if self._lib.rmx_last_timing_kind(self._ctx, kind, C.byref(name), C.byref(ms), C.byref(n)) != 0:
+                break
+            if n.value:
+                out[name.value.decode()] = {"ms": ms.value, "launches": n.value}
+            kind += 1
+        return out
 
     def _check_iq(self, iq):
         """Shape/dtype check of a host window array before its pointer goes to C (which reads

@@ -85,3 +85,57 @@ def test_job_shard_weak_and_strong():
             assert all(blocks[r + 1][0] == blocks[r][0] + blocks[r][1] for r in range(n - 1))
             assert max(b[1] for b in blocks) - min(b[1] for b in blocks) <= 1
     assert bench.job_shard("cfg5", "strong", 16, 1, 2) == (8, 8, 16)
+
+
+def test_projection_table_arithmetic():
+    """strong_scaling_projection: G GPUs on a job without a collective = one GPU on ceil(W / G) windows;
+    efficiency = time(1) / (G * time(G))."""
+    import bench
+    t = bench.projection_table({1: 1.6, 2: 0.82, 4: 0.44, 8: 0.25}, 4096)
+    assert list(t) == ["1", "2", "4", "8"]
+    assert [t[g]["windows_per_gpu"] for g in t] == [4096, 2048, 1024, 512]
+    assert t["1"]["efficiency_vs_G1"] == 1.0
+    assert abs(t["2"]["efficiency_vs_G1"] - 1.6 / (2 * 0.82)) < 1e-12
+    assert abs(t["8"]["efficiency_vs_G1"] - 0.8) < 1e-12
+    assert bench.projection_table({1: 1.0, 3: 0.4}, 100)["3"]["windows_per_gpu"] == 34
+
+
+def test_binary_carries_the_digest_of_its_sources(tmp_path):
+    """VERDICT r04 #4b: the library names the sources it was built from (rmx_build_info, compiled in by
+    __graft_entry__.build), staleness is decided by that digest and not by mtimes, and bench.py refuses a binary whose
+    digest is not the tree's."""
+    import __graft_entry__ as ge
+    from radio_mapper_amd import xcorr
+    d = ge.source_digest()
+    assert len(d) == 16 and int(d, 16) >= 0
+    assert ge.binary_digest() == d, "librmx_hip.so is stale: run __graft_entry__.build()"
+    assert xcorr.build_info()["source_digest"] == d and xcorr.build_info()["arch"] == "gfx950"
+    assert not ge._stale()
+    # a file without the marker, a missing file, a file with another digest: all stale
+    (tmp_path / "empty.so").write_bytes(b"\x7fELF nothing here")
+    assert ge.binary_digest(str(tmp_path / "empty.so")) is None and ge._stale(str(tmp_path / "empty.so"))
+    assert ge._stale(str(tmp_path / "missing.so"))
+    (tmp_path / "other.so").write_bytes(b"xx RMX_BUILD_INFO source_digest=0123456789abcdef arch=gfx950\0")
+    assert ge.binary_digest(str(tmp_path / "other.so")) == "0123456789abcdef" and ge._stale(str(tmp_path / "other.so"))
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "sys.exit(3)" in src[src.index("build_info = xcorr.build_info()"):src.index("dev = torch.device(\"cuda\", dev_index)")]
+
+
+def test_recorded_valu_fraction(tmp_path, monkeypatch):
+    """roofline.valu (VERDICT r04 #4c): wave-instructions x 2 cycles / (1024 SIMDs x 2.4 GHz) over the launch time."""
+    import importlib
+    import bench
+    importlib.reload(bench)
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "source_digest", lambda: "a" * 16)
+    assert bench.recorded_valu(1.7) is None
+    (prof / "pmc_latest.json").write_text(json.dumps({"kernel": "k_win", "tag": "rXX", "source_digest": "a" * 16,
+                                                      "counters": {"SQ_INSTS_VALU": 9.03e8}}))
+    v = bench.recorded_valu(1.685)
+    assert abs(v["issue_ms_at_2cyc"] - 9.03e8 * 2 / (1024 * 2.4e9) * 1e3) < 1e-12
+    assert abs(v["frac_of_launch"] - v["issue_ms_at_2cyc"] / 1.685) < 1e-12 and 0.4 < v["frac_of_launch"] < 0.5
+    (prof / "pmc_latest.json").write_text(json.dumps({"kernel": "k_win", "tag": "old", "source_digest": "b" * 16,
+                                                      "counters": {"SQ_INSTS_VALU": 9.03e8}}))
+    assert "stale" in bench.recorded_valu(1.685)

@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 import radio_mapper_amd as rm
+from conftest import near_tie_windows
 from oracle import xcorr_ref as orc
 
 pytestmark = pytest.mark.gpu
@@ -110,7 +111,12 @@ def test_edge_cases_n256_fixture(xc, golden_dir):
     # the last bit of whichever FFT computed them (the fixture, i.e. pocketfft, records -7).  Which of two such
     # values is larger is not part of the path's definition; the tie RULE (lowest 'full' index) is, and it is
     # enforced where the kernel reproduces a tie exactly: test_exact_tie_resolves_to_lowest_index.
-    assert int(g["lag_int"][4, 0]) == -7 and li[4, 0] in (-7, 9) and li[5, 0] == 0
+    # Written through the oracle like every seeded test (VERDICT r04 #7a): the oracle's own two largest magnitudes must be
+    # within 1e-5 of each other, and the GPU's lag must be the oracle's first or its second candidate -- nothing else.
+    margin4, first4, second4 = orc.peak_top2(iq[4, 0], iq[4, 1])
+    assert int(g["lag_int"][4, 0]) == first4 == -7 and second4 == 9 and margin4 <= TOL
+    assert li[4, 0] == first4 or (margin4 <= TOL and li[4, 0] == second4)
+    assert li[5, 0] == 0
     assert np.allclose(pk[1:], g["peak"][1:], rtol=1e-5)
     # fractional lag of every window against the reference-generated values (windows 0, 2, 3: exactly 0
     # by the edge / flat-top rule; 1, 4: isolated impulses, the neighbour taps are round-off of a peak of
@@ -155,7 +161,10 @@ def test_edge_cases_n4096(xc):
     assert li[1, 0] == ri[1, 0] == 20
     assert li[2, 0] == ri[2, 0] == N - 1 and lf[2, 0] == 0.0
     assert li[3, 0] == ri[3, 0] == -(N - 1) and lf[3, 0] == 0.0
-    assert li[4, 0] in (-7, 9)              # a tie only up to each FFT's last bit (see test_edge_cases_n256_fixture)
+    # a tie only up to each FFT's last bit (see test_edge_cases_n256_fixture): the oracle's first or second candidate
+    margin4, first4, second4 = orc.peak_top2(e[4, 0], e[4, 1])
+    assert ri[4, 0] == first4 and {first4, second4} == {-7, 9} and margin4 <= TOL
+    assert li[4, 0] == first4 or li[4, 0] == second4
     # constant inputs -> triangular |r|: the parabola's curvature is 2/N of its height, so one float32
     # ulp of tap asymmetry moves the vertex by eps32 * N/4 = 1.2e-4 samples.  The bar for such a
     # flat top is the 1e-5 of the spec OR 4 ulp of tap error through that conditioning.
@@ -408,6 +417,67 @@ def test_error_codes_on_device(xc):
     with pytest.raises(xc.RmxError) as e:
         xc.XcorrEngine(3, 4096, 4, device=99)
     assert e.value.code == -1
+
+
+@pytest.mark.parametrize("shape", [(8, 4096, 300), (3, 4096, 5), (3, 1024, 40), (3, 65536, 6)])
+def test_mixed_pointer_flags_through_the_raw_abi(xc, shape):
+    """VERDICT r04 #7c: rmx_xcorr_batch accepts RMX_IN_DEVICE alone (device windows, host results) and RMX_OUT_DEVICE alone
+    (host windows, device results); the binding only ever passes both or neither.  Raw ctypes calls of all four forms on
+    one ctx -- fused N = 4096 with a partial round, the small-batch route, a whole-window kernel, the four-step path --
+    must give identical arrays, equal to the oracle's."""
+    import ctypes as C
+    import torch
+    B, N, W = shape
+    iq = rm.synth.make_windows(W, B, N, 10e6, seed=sum(shape))[0]
+    ri, rf, rp = orc.xcorr_batch_fast(iq, workers=8)
+    P = B * (B - 1) // 2
+    lib = xc.load_library()
+    dev = torch.device("cuda", 0)
+    x_d = torch.from_numpy(np.ascontiguousarray(iq).view(np.float32).reshape(W, B, N, 2)).to(dev)
+    got = {}
+    with xc.XcorrEngine(B, N, W) as eng:
+        eng.set_stream(torch.cuda.current_stream().cuda_stream)
+        for flags in (0, xc.RMX_IN_DEVICE, xc.RMX_OUT_DEVICE, xc.RMX_IN_DEVICE | xc.RMX_OUT_DEVICE):
+            in_ptr = C.c_void_p(x_d.data_ptr()) if flags & xc.RMX_IN_DEVICE else iq.ctypes.data_as(C.c_void_p)
+            if flags & xc.RMX_OUT_DEVICE:
+                o = [torch.full((W, P), -77, dtype=torch.int32, device=dev), torch.full((W, P), -77.0, device=dev),
+                     torch.full((W, P), -77.0, device=dev)]
+                ptrs = [C.c_void_p(t.data_ptr()) for t in o]
+            else:
+                o = [np.full((W, P), -77, np.int32), np.full((W, P), -77, np.float32), np.full((W, P), -77, np.float32)]
+                ptrs = [a.ctypes.data_as(C.c_void_p) for a in o]
+            rc = lib.rmx_xcorr_batch(eng._ctx, in_ptr, W, None, 0, ptrs[0], ptrs[1], ptrs[2], flags)
+            assert rc == 0, (flags, lib.rmx_last_error(eng._ctx))
+            assert lib.rmx_synchronize(eng._ctx) == 0
+            got[flags] = [t.cpu().numpy() if flags & xc.RMX_OUT_DEVICE else t for t in o]
+    _assert_parity(*got[0], ri, rf, rp)
+    for flags in (1, 2, 3):
+        for a, b in zip(got[0], got[flags]):
+            assert np.array_equal(a, b), flags
+
+
+@pytest.mark.parametrize("N", [256, 4096, 16384])
+def test_abs_squared_search_near_ties(xc, N):
+    """VERDICT r04 #7d.  The kernels search the maximum of |c|^2 (one fma per lag) and take the square root of the winner
+    and its two neighbours only; numpy searches the maximum of |c| = hypot(re, im) rounded to float32.  Rounding the root
+    can merge two different squares into one float32 |c| (numpy then takes the LOWER index) or order them either way, so
+    on candidates a few ulp apart the two definitions may disagree.  Pinned expectation: whenever the GPU's lag is not the
+    oracle's, the oracle's own two largest magnitudes are within 1e-5 and the GPU took the oracle's second candidate; peak
+    values agree to 1e-5 either way; and the deviation never shows on anything wider than 1e-6 (k = +-4 ulp cases are
+    checked to be inside that band, i.e. the construction really produces near-ties)."""
+    e = near_tie_windows(N, 31 + N)
+    ri, rf, rp = orc.xcorr_batch_literal(e)
+    pl = orc.pair_list(2)
+    margin, second = _top2(e, pl)
+    assert np.all(margin <= 1e-6), margin.ravel()            # the construction: all nine windows are near-ties
+    with xc.XcorrEngine(2, N, e.shape[0]) as eng:
+        li, lf, pk = eng.correlate(e)
+    bad = li != ri
+    assert np.all(li[bad] == second[bad]), (li.ravel(), ri.ravel(), second.ravel())
+    assert np.allclose(pk, rp, rtol=1e-5)
+    ok = ~bad
+    got, ref = li + lf.astype(np.float64), ri + rf
+    assert np.all(np.abs(got[ok] - ref[ok]) <= TOL * np.maximum(np.abs(ref[ok]), 1.0))
 
 
 @pytest.mark.parametrize("logn", [21, 22])
@@ -923,6 +993,55 @@ def test_partial_round_with_small_chunks(xc, opts, chunk):
     assert np.allclose(got[1], fused[1], atol=2e-5) and np.allclose(got[2], fused[2], rtol=1e-5)
 
 
+def test_per_launch_timing_over_many_partial_rounds(xc, opts):
+    """with option timing = 1 every launch is bracketed by two HIP events; the pool used to be sized
+    ahead of the chunk loop for at most ONE partial round per call.  chunk_windows = 300 over 5 x 300 + 44 windows of 8
+    buoys: every chunk has a partial round of its own (three launches per chunk when it takes the per-transform route).
+    The event pool now grows in front of every record; results as without timing, and the per-family read-back adds up."""
+    n_cus = _device_cus()
+    B, chunk = 8, n_cus + 44
+    W = 5 * chunk + 44
+    iq, ri, rf, rp = _tiled_batch(B, W, 99)
+    opts("chunk_windows", chunk)
+    with xc.XcorrEngine(B, 4096, W) as eng:
+        plain = _correlate_dev(eng, iq)
+        eng.set_option("timing", 1)
+        timed = _correlate_dev(eng, iq)
+        tm = eng.last_timing()
+        fam = eng.last_timing_by_kernel()
+        timed2 = _correlate_dev(eng, iq)
+    _assert_parity(*timed, ri, rf, rp)
+    for a, b, c in zip(plain, timed, timed2):
+        assert np.array_equal(a, b) and np.array_equal(a, c)
+    # six chunks (5 x (CUs + 44) + 44 windows): all fused = 6 launches; with the split route the five large chunks run one
+    # fused round + forward + pairs each and the last chunk (44 windows, behind full rounds) forward + pairs only = 17
+    assert (tm["fwd_launches"], tm["pair_launches"]) in ((0, 6), (6, 11)), tm
+    assert set(fam) <= {"k_fwd", "k_win|k_pair"} and fam["k_win|k_pair"]["launches"] == tm["pair_launches"]
+    assert abs(fam["k_win|k_pair"]["ms"] - tm["pair_ms"]) < 1e-3 and tm["pair_ms"] > 0.0
+
+
+def test_timing_by_kernel_family_on_the_other_paths(xc):
+    """rmx_last_timing_kind on the whole-window, four-step and CAF paths: the families that ran, each with a positive time."""
+    cases = ((3, 1024, 64, {"g_win_*"}),                                   # g_win_fused
+             (3, 65536, 8, {"g_cols_fwd", "g_rows_fused", "g_cols_inv", "g_final"}),
+             (8, 65536, 2, {"g_cols_fwd", "g_rows_fwd", "g_rows_anchor", "g_cols_inv", "g_final"}))
+    for B, N, W, want in cases:
+        iq = rm.synth.make_windows(W, B, N, 2.4e6, seed=N + B)[0]
+        with xc.XcorrEngine(B, N, W) as eng:
+            eng.set_option("timing", 1)
+            eng.correlate(iq)
+            fam = eng.last_timing_by_kernel()
+        assert set(fam) == want, (B, N, W, fam)
+        assert all(v["ms"] > 0.0 and v["launches"] >= 1 for v in fam.values())
+    B, N, W, D = 4, 4096, 2, 5
+    iq = rm.synth.make_windows(W, B, N, 2.4e6, seed=5)[0]
+    with xc.XcorrEngine(B, N, W) as eng:
+        eng.set_option("timing", 1)
+        eng.caf(iq, (np.arange(D) - 2) * 50.0 / 2.4e6)
+        fam = eng.last_timing_by_kernel()
+    assert set(fam) == {"k_fwd", "k_win|k_pair", "k_caf_select"} and fam["k_fwd"]["launches"] == 2
+
+
 def test_caf_all_hypotheses_in_one_launch(xc):
     """N = 4096, one chunk: rmx_caf_batch runs every hypothesis in one forward and one pair launch (virtual window =
     hypothesis x window).  Against the oracle's per-hypothesis loop on 8 buoys x 3 windows x 21 hypotheses with true offsets
@@ -949,7 +1068,9 @@ def test_caf_all_hypotheses_in_one_launch(xc):
                 alt = orc.xcorr_pair(iq[w, i], y)[2]
                 assert abs(float(alt) - float(rp[w, q])) <= 1e-5 * float(rp[w, q]), (w, q)
             same = (gd == rd) & (li == ri)
-            assert same.mean() > 0.95
+            # a COUNT, not a fraction (VERDICT r04 #7b): two hypotheses tie to 1e-5 only when the true offset sits within
+            # ~0.04 Hz of the middle between two grid points -- about one pair-window in a thousand
+            assert int((~same).sum()) <= 2, int((~same).sum())
             ref = (ri + rf)[same]
             assert np.all(np.abs((li + lf.astype(np.float64))[same] - ref) <= TOL * np.maximum(np.abs(ref), 1.0))
             assert np.allclose(pk[same], rp[same], rtol=1e-5)

@@ -293,3 +293,31 @@ def test_triangulate_position_against_reference_results(tri, name):
     # and the fix is the transmitter the scenario was built from (noise-free cases: centimetres)
     _, dist = tp.GeodeticCalculator.bearing_distance(got.estimated_lat, got.estimated_lng, *sc["transmitter"][:2])
     assert dist < (0.05 if sc["sigma_m"] == 0 else 10 * sc["sigma_m"])
+
+
+def test_a_cut_below_the_shortest_reference_excerpt_is_refused(conv, monkeypatch, caplog):
+    """one 17-sample excerpt must not turn a 256-sample group into a 16-sample, noise-dominated correlation.
+    The reference's clipping (iq_stream_client.py:306-313) leaves at least 129 samples, so 128 is the shortest legitimate
+    cut: below it the group is logged and yields nothing; min_cut_samples is a constructor parameter; equal power-of-two
+    windows shorter than that (the caller's own choice, no cut) are still correlated."""
+    p = _proc(conv)
+    calls = []
+
+    def fake(iq, pairs=None):
+        iq = np.asarray(iq)
+        calls.append(iq.shape)
+        W, B = iq.shape[:2]
+        P = B * (B - 1) // 2
+        return np.zeros((W, P), np.int32), np.zeros((W, P), np.float32), np.ones((W, P), np.float32)
+
+    monkeypatch.setattr(p.tdoa_calculator, "measure_lags", fake)
+    dets = _iq_dets(conv, 121.5, n=256, seed=11)
+    dets[1].iq_samples = dets[1].iq_samples[:17]
+    with caplog.at_level("ERROR"):
+        assert p.tdoa_calculator.calculate_tdoa_measurements(dets, p.buoy_positions) == []
+    assert not calls and any("common cut of 16 is below 128" in r.message for r in caplog.records)
+    dets[1].iq_samples = _iq_dets(conv, 121.5, n=256, seed=11)[1].iq_samples[:129]
+    assert len(p.tdoa_calculator.calculate_tdoa_measurements(dets, p.buoy_positions)) == 3 and calls[-1] == (1, 3, 128)
+    short = _iq_dets(conv, 121.5, n=64, seed=12)                      # equal lengths: no cut, no minimum
+    assert len(p.tdoa_calculator.calculate_tdoa_measurements(short, p.buoy_positions)) == 3 and calls[-1] == (1, 3, 64)
+    assert tp.TDoACalculator(min_cut_samples=16).min_cut_samples == 16 and tp.TDoACalculator().min_cut_samples == 128
