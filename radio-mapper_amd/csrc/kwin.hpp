@@ -71,10 +71,21 @@ __device__ __forceinline__ void load_tw1(float2 (&tw1)[16], const float4* __rest
 // in another wave.  The pair's winner is resolved by one lane after the NEXT pair's barrier.
 constexpr int kLdsWinImg = kLdsXchg;                                 // 69632 each, two of them
 constexpr int kLdsWinTw2 = 2 * kLdsWinImg;
+#ifndef RMX_KWIN_PEAK1
+// Peak search, second generation (round 5): a wave only finds its maximum and the LANE that holds it; that lane and its
+// two neighbours l*-2, l*+2 park their sixteen |r|^2 beside the halo rows, and the slot, the 'full' index and the taps are
+// worked out by the resolver (once per batch, on one of the early waves) instead of by sixteen compares + sixteen selects
+// in every lane of every pair.  Seven rows per wave and slot instead of four: the ring shrinks to 4 slots, batches of 3.
+constexpr int kResSlots = 4;
+constexpr int kResBatch = 3;
+constexpr int kHaloRows = 7;   // lanes 0, 1, 62, 63, then l*-2, l*, l*+2
+#else
 constexpr int kResSlots = 8;   // record ring; winners are resolved in batches of kResBatch pairs
 constexpr int kResBatch = 7;   // < kResSlots: the pair after a batch writes a slot the resolver is not reading
-constexpr int kLdsWinHalo = kLdsWinTw2 + kLdsTw2;                           // [slots][8][4][16] float
-constexpr int kLdsWinRed = kLdsWinHalo + kResSlots * 8 * 4 * 16 * 4;        // [slots][8] float4
+constexpr int kHaloRows = 4;
+#endif
+constexpr int kLdsWinHalo = kLdsWinTw2 + kLdsTw2;                           // [slots][8][rows][16] float
+constexpr int kLdsWinRed = kLdsWinHalo + kResSlots * 8 * kHaloRows * 16 * 4;   // [slots][8] float4
 constexpr int kLdsWinOidx = kLdsWinRed + kResSlots * 8 * 16;                // [slots] int: output slot of the pair
 constexpr int kLdsWinBytes = kLdsWinOidx + kResSlots * 4;
 static_assert(kLdsWinBytes <= 160 * 1024, "k_win LDS");
@@ -122,7 +133,7 @@ __device__ __forceinline__ void resolve_batch(int lane, const float4* red, const
         k_to_owner(kk, tt, q);
         const int ln = tt & 63;
         const int row = ln < 2 ? ln : (ln >= 62 ? ln - 60 : 0);
-        return halo[(((slot * 8 + (tt >> 6)) * 4) + row) * 16 + q];
+        return halo[(((slot * 8 + (tt >> 6)) * kHaloRows) + row) * 16 + q];
     };
     const int kc = win ? k : (kM - 1);
     const float hm = halo_tap(kc - 1), hp = halo_tap(kc + 1);
@@ -138,6 +149,71 @@ __device__ __forceinline__ void resolve_batch(int lane, const float4* red, const
         peak[obase + out] = b;
     }
 }
+
+#ifndef RMX_KWIN_PEAK1
+// The same for the second-generation records: red[slot][wave] = {max |r|^2 of the wave, the lane l* that holds it}; the
+// halo block holds per (slot, wave) seven rows of sixteen |r|^2: lanes 0, 1, 62, 63 (rows 0-3) and l*-2, l*, l*+2 (rows 4-6,
+// where those are not halo lanes themselves).  lane = 8*g + r works on wave r's record of the g-th pair of the batch: the
+// slot is the lowest one of l*'s row that equals the maximum, the 'full' index follows from (wave, lane, slot).
+__device__ __forceinline__ void resolve_batch2(int lane, const float4* red, const float* halo, const int* oidx,
+                                               int first, int cnt, long obase, float out_scale,
+                                               int* __restrict__ lag_int, float* __restrict__ lag_frac,
+                                               float* __restrict__ peak) {
+    const int g = lane >> 3, r = lane & 7;
+    const bool act = g < cnt;
+    const int slot = (first + g) & (kResSlots - 1);
+    const float* rf = reinterpret_cast<const float*>(red) + 4 * (slot * 8 + r);
+    const float ex_raw = rf[0];
+    const int ls = reinterpret_cast<const int*>(rf)[1] & 63;
+    auto row_of = [&](int ln) -> int { return ln < 2 ? ln : (ln >= 62 ? ln - 60 : 5); };
+    const float4* wrow = reinterpret_cast<const float4*>(halo + ((slot * 8 + r) * kHaloRows + row_of(ls)) * 16);
+    int qs = 15;
+#pragma unroll
+    for (int j = 3; j >= 0; --j) {          // descending: the lowest slot wins
+        const float4 v = wrow[j];
+        if (v.w == ex_raw) qs = 4 * j + 3;
+        if (v.z == ex_raw) qs = 4 * j + 2;
+        if (v.y == ex_raw) qs = 4 * j + 1;
+        if (v.x == ex_raw) qs = 4 * j;
+    }
+    const int tw = r * 64 + ls, pw = tw & 1, uw = tw >> 1;
+    const float ex = act ? ex_raw : -3.0f;
+    const int k = act ? (pw ? uw - 1 : uw + kM - 1) + 256 * qs : 0x7fffffff;
+    const int out = oidx[slot];
+    float gmax = ex;                                     // max over the 8 lanes of the group
+    gmax = fmaxf(gmax, __builtin_bit_cast(float, dpp_i<0xB1>(__builtin_bit_cast(int, gmax))));
+    gmax = fmaxf(gmax, __builtin_bit_cast(float, dpp_i<0x4E>(__builtin_bit_cast(int, gmax))));
+    gmax = fmaxf(gmax, __builtin_bit_cast(float, dpp_i<0x141>(__builtin_bit_cast(int, gmax))));
+    int kstar = (ex == gmax) ? k : 0x7fffffff;
+    kstar = min(kstar, dpp_i<0xB1>(kstar));
+    kstar = min(kstar, dpp_i<0x4E>(kstar));
+    kstar = min(kstar, dpp_i<0x141>(kstar));
+    const bool win = act && ex == gmax && k == kstar;     // exactly one lane per active group
+    // neighbour taps k*-1, k*+1: lanes l*-2 / l*+2 of the winner's wave (rows 4 / 6), or a halo lane of some wave
+    auto tap = [&](int kk) -> float {
+        kk = kk < 0 ? 0 : (kk > 2 * kM - 2 ? 2 * kM - 2 : kk);
+        int tt, q;
+        k_to_owner(kk, tt, q);
+        const int ln = tt & 63;
+        int row = ln < 2 ? ln : (ln >= 62 ? ln - 60 : 5 + ((ln - ls) >> 1));
+        row = row < 0 ? 0 : (row > kHaloRows - 1 ? kHaloRows - 1 : row);   // (lanes that lost their group compute garbage: keep it inside)
+        return halo[((slot * 8 + (tt >> 6)) * kHaloRows + row) * 16 + q];
+    };
+    const int kc = win ? k : (kM - 1);
+    const float tm = tap(kc - 1), tp = tap(kc + 1);
+    const float b = sqrtf(fmaxf(ex, 0.0f)) * out_scale;
+    const float a = sqrtf(fmaxf(tm, 0.0f)) * out_scale;
+    const float c = sqrtf(fmaxf(tp, 0.0f)) * out_scale;
+    const double den = (double)a - 2.0 * (double)b + (double)c;
+    float frac = 0.0f;
+    if (kc > 0 && kc < 2 * kM - 2 && den != 0.0) frac = (float)(0.5 * ((double)a - (double)c) / den);
+    if (win) {
+        lag_int[obase + out] = kc - (kM - 1);
+        lag_frac[obase + out] = frac;
+        peak[obase + out] = b;
+    }
+}
+#endif
 
 #ifdef RMX_KWIN_STAMPS
 // diagnostic build (tools/probe/kwin_bench.hip -DRMX_KWIN_STAMPS): shader-clock stamps of workgroup's wave 0 at the phase
@@ -264,9 +340,17 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
         if (!(dbg & 1)) __syncthreads();
 #endif
         if (npend == kResBatch || (flush && npend > 0)) {
+#ifndef RMX_KWIN_PEAK1
+            // one of waves 0-3: they reach every barrier ~950 ticks ahead of waves 4-7 (the older wave of a SIMD wins every
+            // arbiter), so the resolve is paid out of their waiting time
+            if (!(dbg & 2) && !(dbg & 256) && wave == (seq & 3))
+                resolve_batch2(lane, red, halo, oidx, (npair - npend) & (kResSlots - 1), npend, obase, out_scale, lag_int,
+                               lag_frac, peak);
+#else
             if (!(dbg & 2) && !(dbg & 256) && wave == (seq & 7))
                 resolve_batch(lane, red, halo, oidx, (npair - npend) & (kResSlots - 1), npend, obase, out_scale, lag_int,
                               lag_frac, peak);
+#endif
             npend = 0;
         }
     };
@@ -560,8 +644,67 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
             ++npend; ++npair;
             return;
         }
+#ifndef RMX_KWIN_PEAK1
+        {
+            // lane maximum (8 x v_max3_f32), row maxima by four DPP steps, wave maximum on the scalar unit: |r|^2 >= +0 and
+            // the one sentinel is -1, so the float order is the signed-integer order of the bit patterns (s_max_i32)
+            float tmax, wrow;
+            asm volatile("v_max3_f32 %[t], %[m0], %[m1], %[m2]\n\tv_max3_f32 %[w], %[m3], %[m4], %[m5]\n\t"
+                         "v_max3_f32 %[t], %[t], %[m6], %[m7]\n\tv_max3_f32 %[w], %[w], %[m8], %[m9]\n\t"
+                         "v_max3_f32 %[t], %[t], %[ma], %[mb]\n\tv_max3_f32 %[w], %[w], %[mc], %[md]\n\t"
+                         "v_max3_f32 %[t], %[t], %[me], %[mf]\n\tv_max_f32 %[t], %[t], %[w]\n\t"
+                         "s_nop 1\n\t"
+                         "v_max_f32_dpp %[w], %[t], %[t] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                         "v_max_f32_dpp %[w], %[w], %[w] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                         "v_max_f32_dpp %[w], %[w], %[w] row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                         "v_max_f32_dpp %[w], %[w], %[w] row_mirror row_mask:0xf bank_mask:0xf"
+                         : [t] "=&v"(tmax), [w] "=&v"(wrow)
+                         : [m0] "v"(mag[0]), [m1] "v"(mag[1]), [m2] "v"(mag[2]), [m3] "v"(mag[3]), [m4] "v"(mag[4]),
+                           [m5] "v"(mag[5]), [m6] "v"(mag[6]), [m7] "v"(mag[7]), [m8] "v"(mag[8]), [m9] "v"(mag[9]),
+                           [ma] "v"(mag[10]), [mb] "v"(mag[11]), [mc] "v"(mag[12]), [md] "v"(mag[13]), [me] "v"(mag[14]),
+                           [mf] "v"(mag[15]));
+            const int wi = __builtin_bit_cast(int, wrow);   // every lane: the max of its row of 16
+            const int wmaxi = max(max(__builtin_amdgcn_readlane(wi, 0), __builtin_amdgcn_readlane(wi, 16)),
+                                  max(__builtin_amdgcn_readlane(wi, 32), __builtin_amdgcn_readlane(wi, 48)));
+            const unsigned long long hit = __ballot(__builtin_bit_cast(int, tmax) == wmaxi);
+            int ls;
+            if (__builtin_expect(__popcll(hit) == 1, 1)) {
+                ls = __ffsll((long long)hit) - 1;
+            } else {
+                // several lanes hold the maximum exactly (an exact tie, or an all-zero window): the lowest 'full' index decides,
+                // found the old way -- lowest slot per lane, wave minimum of the indices
+                const float wmaxf = __builtin_bit_cast(float, wmaxi);
+                int qa = 16, qb = 16, qc = 16, qd = 16;
+                argsel4<12>(qa, qb, qc, qd, mag[12], mag[13], mag[14], mag[15], wmaxf);
+                argsel4<8>(qa, qb, qc, qd, mag[8], mag[9], mag[10], mag[11], wmaxf);
+                argsel4<4>(qa, qb, qc, qd, mag[4], mag[5], mag[6], mag[7], wmaxf);
+                argsel4<0>(qa, qb, qc, qd, mag[0], mag[1], mag[2], mag[3], wmaxf);
+                const int qsel = min(min(qa, qb), min(qc, qd));
+                const int kw = wave_min_i32(qsel < 16 ? kbase + qsel * 256 : 0x7fffffff);
+                int ts, qs;
+                k_to_owner(kw, ts, qs);
+                ls = ts & 63;
+            }
+            ls = __builtin_amdgcn_readfirstlane(ls);
+            // rows: the halo lanes always, l*-2 / l* / l*+2 where they are not halo lanes (whose row the resolver reads instead)
+            const int d = lane - ls + 2;                       // 0, 2, 4
+            const bool near = (unsigned)d <= 4u && !(d & 1);
+            if ((is_halo || near) && !(dbg & 512)) {
+                const int row = is_halo ? hl : 4 + (d >> 1);
+                float4* hp = reinterpret_cast<float4*>(halo + ((rb * 8 + wave) * kHaloRows + row) * 16);
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4)
+                    hp[q4] = make_float4(mag[4 * q4], mag[4 * q4 + 1], mag[4 * q4 + 2], mag[4 * q4 + 3]);
+            }
+            if (lane == 0) {
+                const u32x2 rec = {(unsigned)wmaxi, (unsigned)ls};
+                *reinterpret_cast<u32x2*>(red + rb * 8 + wave) = rec;
+                if (wave == 0) oidx[rb] = out_idx;
+            }
+        }
+#else
         if (is_halo && !(dbg & 512)) {
-            float4* hp = reinterpret_cast<float4*>(halo + ((rb * 8 + wave) * 4 + hl) * 16);
+            float4* hp = reinterpret_cast<float4*>(halo + ((rb * 8 + wave) * kHaloRows + hl) * 16);
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4)
                 hp[q4] = make_float4(mag[4 * q4], mag[4 * q4 + 1], mag[4 * q4 + 2], mag[4 * q4 + 3]);
@@ -650,6 +793,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
             *reinterpret_cast<u32x4*>(red + rb * 8 + wave) = rec;
             if (wave == 0) oidx[rb] = out_idx;
         }
+#endif   // RMX_KWIN_PEAK1
         ++npend;
         ++npair;
     };

@@ -1023,7 +1023,7 @@ def test_per_launch_timing_over_many_partial_rounds(xc, opts):
 def test_timing_by_kernel_family_on_the_other_paths(xc):
     """rmx_last_timing_kind on the whole-window, four-step and CAF paths: the families that ran, each with a positive time."""
     cases = ((3, 1024, 64, {"g_win_*"}),                                   # g_win_fused
-             (3, 65536, 8, {"g_cols_fwd", "g_rows_fused", "g_cols_inv", "g_final"}),
+             (3, 65536, 64, {"g_cols_fwd", "g_rows_fused", "g_cols_inv", "g_final"}),
              (8, 65536, 2, {"g_cols_fwd", "g_rows_fwd", "g_rows_anchor", "g_cols_inv", "g_final"}))
     for B, N, W, want in cases:
         iq = rm.synth.make_windows(W, B, N, 2.4e6, seed=N + B)[0]

@@ -244,8 +244,15 @@ int main(int argc, char** argv) {
                 printf("    stamps (s_memtime ticks, mean over %d windows): phase 1 %.0f  phase 2 %.0f  whole window %.0f\n", n, p1 / n, p2 / n, tot / n);
             }
 #endif
-            printf("[%d] %-44s %.4f ms  frac %.4f | lags != generator %ld, vs variant 0: lag_int %ld lag_frac %ld peak %ld differ\n", round,
-                   v.name, ms, alg_bytes / (ms * 1e-3) / 8e12, bad_truth, diff_li, diff_lf, diff_pk);
+            // FNV-1a over the three output arrays: binaries built with different -D switches are compared through it
+            unsigned long long hsum = 1469598103934665603ULL;
+            auto fnv = [&](const void* ptr, size_t nb) {
+                const unsigned char* c = (const unsigned char*)ptr;
+                for (size_t k = 0; k < nb; ++k) { hsum ^= c[k]; hsum *= 1099511628211ULL; }
+            };
+            fnv(li.data(), li.size() * 4); fnv(lf.data(), lf.size() * 4); fnv(pk.data(), pk.size() * 4);
+            printf("[%d] %-44s %.4f ms  frac %.4f | lags != generator %ld, vs variant 0: lag_int %ld lag_frac %ld peak %ld differ | fnv %016llx\n", round,
+                   v.name, ms, alg_bytes / (ms * 1e-3) / 8e12, bad_truth, diff_li, diff_lf, diff_pk, hsum);
             fflush(stdout);
         }
     return 0;
