@@ -71,15 +71,25 @@ __device__ __forceinline__ void load_tw1(float2 (&tw1)[16], const float4* __rest
 // in another wave.  The pair's winner is resolved by one lane after the NEXT pair's barrier.
 constexpr int kLdsWinImg = kLdsXchg;                                 // 69632 each, two of them
 constexpr int kLdsWinTw2 = 2 * kLdsWinImg;
-#ifndef RMX_KWIN_PEAK1
-// Peak search, second generation (round 5): a wave only finds its maximum and the LANE that holds it; that lane and its
-// two neighbours l*-2, l*+2 park their sixteen |r|^2 beside the halo rows, and the slot, the 'full' index and the taps are
-// worked out by the resolver (once per batch, on one of the early waves) instead of by sixteen compares + sixteen selects
-// in every lane of every pair.  Seven rows per wave and slot instead of four: the ring shrinks to 4 slots, batches of 3.
+#ifdef RMX_KWIN_PEAK2
+// Peak search, second generation (round 5, VERDICT r04 #1b/c; an A/B build, NOT the default): a wave only finds its maximum
+// and the LANE that holds it; that lane and its two neighbours l*-2, l*+2 park their sixteen |r|^2 beside the halo rows, and
+// the slot, the 'full' index and the taps are worked out by the resolver (once per batch, on one of the early waves)
+// instead of by sixteen compares + sixteen selects in every lane of every pair.  Seven rows per wave and slot instead of
+// four: the ring shrinks to 4 slots, batches of 3.  Measured (tools/probe/kwin_bench, same box, bit-identical outputs):
+// SQ_INSTS_VALU 9.03e8 -> 8.62e8 per launch (-4.5 %), SQ_WAIT_ANY 3.95e8 -> 4.52e8 (+14 %), 1.675 -> 1.673 ms: the
+// instructions removed come back as waiting -- the interval between two barriers is set by dependent latencies (LDS round
+// trips, the DPP chain, the barrier itself), not by VALU issue slots.  LABNOTES.md R5.1.
 constexpr int kResSlots = 4;
 constexpr int kResBatch = 3;
 constexpr int kHaloRows = 7;   // lanes 0, 1, 62, 63, then l*-2, l*, l*+2
+#ifndef RMX_KWIN_RES_MASK
+#define RMX_KWIN_RES_MASK 3    /* the resolving wave rotates over waves 0-3 (A/B: 7 = over all eight) */
+#endif
 #else
+#ifndef RMX_KWIN_RES_MASK
+#define RMX_KWIN_RES_MASK 7
+#endif
 constexpr int kResSlots = 8;   // record ring; winners are resolved in batches of kResBatch pairs
 constexpr int kResBatch = 7;   // < kResSlots: the pair after a batch writes a slot the resolver is not reading
 constexpr int kHaloRows = 4;
@@ -150,7 +160,7 @@ __device__ __forceinline__ void resolve_batch(int lane, const float4* red, const
     }
 }
 
-#ifndef RMX_KWIN_PEAK1
+#ifdef RMX_KWIN_PEAK2
 // The same for the second-generation records: red[slot][wave] = {max |r|^2 of the wave, the lane l* that holds it}; the
 // halo block holds per (slot, wave) seven rows of sixteen |r|^2: lanes 0, 1, 62, 63 (rows 0-3) and l*-2, l*, l*+2 (rows 4-6,
 // where those are not halo lanes themselves).  lane = 8*g + r works on wave r's record of the g-th pair of the batch: the
@@ -283,6 +293,11 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
     const int kbase = p ? (u - 1) : (u + kM - 1);
     const int hl = lane < 2 ? lane : lane - 60;            // halo row of lanes 0,1,62,63
     const bool is_halo = lane < 2 || lane >= 62;
+#ifdef RMX_KWIN_PEAK2
+    const int peak_ca = is_halo ? hl * 64 : lane * 32 + 320;   // row byte offset of this lane's |r|^2 row = peak_ca - peak_cb * l*
+    const int peak_cb = is_halo ? 0 : 32;
+    const int wave_halo = __builtin_amdgcn_readfirstlane(wave * (kHaloRows * 64));
+#endif
     __syncthreads();
 #ifndef RMX_TW2_LDS
     // this thread's TW2 row W_256^(n0*k1), k1 = 0..15, kept in registers for the whole launch (30 of the 60 VGPRs
@@ -340,14 +355,14 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
         if (!(dbg & 1)) __syncthreads();
 #endif
         if (npend == kResBatch || (flush && npend > 0)) {
-#ifndef RMX_KWIN_PEAK1
+#ifdef RMX_KWIN_PEAK2
             // one of waves 0-3: they reach every barrier ~950 ticks ahead of waves 4-7 (the older wave of a SIMD wins every
             // arbiter), so the resolve is paid out of their waiting time
-            if (!(dbg & 2) && !(dbg & 256) && wave == (seq & 3))
+            if (!(dbg & 2) && !(dbg & 256) && wave == (seq & RMX_KWIN_RES_MASK))
                 resolve_batch2(lane, red, halo, oidx, (npair - npend) & (kResSlots - 1), npend, obase, out_scale, lag_int,
                                lag_frac, peak);
 #else
-            if (!(dbg & 2) && !(dbg & 256) && wave == (seq & 7))
+            if (!(dbg & 2) && !(dbg & 256) && wave == (seq & RMX_KWIN_RES_MASK))
                 resolve_batch(lane, red, halo, oidx, (npair - npend) & (kResSlots - 1), npend, obase, out_scale, lag_int,
                               lag_frac, peak);
 #endif
@@ -644,7 +659,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
             ++npend; ++npair;
             return;
         }
-#ifndef RMX_KWIN_PEAK1
+#ifdef RMX_KWIN_PEAK2
         {
             // lane maximum (8 x v_max3_f32), row maxima by four DPP steps, wave maximum on the scalar unit: |r|^2 >= +0 and
             // the one sentinel is -1, so the float order is the signed-integer order of the bit patterns (s_max_i32)
@@ -663,9 +678,16 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
                            [m5] "v"(mag[5]), [m6] "v"(mag[6]), [m7] "v"(mag[7]), [m8] "v"(mag[8]), [m9] "v"(mag[9]),
                            [ma] "v"(mag[10]), [mb] "v"(mag[11]), [mc] "v"(mag[12]), [md] "v"(mag[13]), [me] "v"(mag[14]),
                            [mf] "v"(mag[15]));
+            // wave maximum on the scalar unit (four v_readlane, three s_max_i32), winner lane by ballot + s_ff1: everything
+            // behind the DPP steps is one dependent chain, and a dependent instruction costs a wave ~10 cycles where an
+            // independent one costs 4 -- the chain is kept short (first PEAK2 build: ~40 links, no faster than the 75
+            // mostly independent instructions it replaced)
             const int wi = __builtin_bit_cast(int, wrow);   // every lane: the max of its row of 16
-            const int wmaxi = max(max(__builtin_amdgcn_readlane(wi, 0), __builtin_amdgcn_readlane(wi, 16)),
-                                  max(__builtin_amdgcn_readlane(wi, 32), __builtin_amdgcn_readlane(wi, 48)));
+            const int r0 = __builtin_amdgcn_readlane(wi, 0), r1 = __builtin_amdgcn_readlane(wi, 16);
+            const int r2 = __builtin_amdgcn_readlane(wi, 32), r3 = __builtin_amdgcn_readlane(wi, 48);
+            int wmaxi, wtmp;
+            asm("s_max_i32 %0, %2, %3\n\ts_max_i32 %1, %4, %5\n\ts_max_i32 %0, %0, %1"
+                : "=&s"(wmaxi), "=&s"(wtmp) : "s"(r0), "s"(r1), "s"(r2), "s"(r3));
             const unsigned long long hit = __ballot(__builtin_bit_cast(int, tmax) == wmaxi);
             int ls;
             if (__builtin_expect(__popcll(hit) == 1, 1)) {
@@ -683,19 +705,42 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
                 const int kw = wave_min_i32(qsel < 16 ? kbase + qsel * 256 : 0x7fffffff);
                 int ts, qs;
                 k_to_owner(kw, ts, qs);
-                ls = ts & 63;
+                ls = __builtin_amdgcn_readfirstlane(ts & 63);
             }
-            ls = __builtin_amdgcn_readfirstlane(ls);
-            // rows: the halo lanes always, l*-2 / l* / l*+2 where they are not halo lanes (whose row the resolver reads instead)
-            const int d = lane - ls + 2;                       // 0, 2, 4
-            const bool near = (unsigned)d <= 4u && !(d & 1);
-            if ((is_halo || near) && !(dbg & 512)) {
-                const int row = is_halo ? hl : 4 + (d >> 1);
-                float4* hp = reinterpret_cast<float4*>(halo + ((rb * 8 + wave) * kHaloRows + row) * 16);
+            // rows: the halo lanes always, l*-2 / l* / l*+2 where they are not halo lanes (whose row the resolver reads
+            // instead).  Writers' mask on the scalar unit: bits l*-2, l*, l*+2 (what falls off either end of the shifts is a
+            // halo lane or no lane) | lanes 0, 1, 62, 63.  Row byte offset: halo lanes hl * 64; the others
+            // (4 + (lane - l* + 2) / 2) * 64 = lane * 32 + 320 - l* * 32, i.e. peak_ca - peak_cb * l* with two per-lane constants.
+            const unsigned long long wmask = ((0x15ull << ls) >> 2) | 0xC000000000000003ull;
+            const int sbase = kLdsWinHalo + rb * (8 * kHaloRows * 64) + wave_halo;   // (scalar: wave_halo is held in an SGPR)
+#ifndef RMX_ABLATE
+            {
+                int addr;
+                unsigned long long sv;
+                const f32x4 d0 = {mag[0], mag[1], mag[2], mag[3]}, d1 = {mag[4], mag[5], mag[6], mag[7]};
+                const f32x4 d2 = {mag[8], mag[9], mag[10], mag[11]}, d3 = {mag[12], mag[13], mag[14], mag[15]};
+                asm volatile("v_mad_i32_i24 %[a], %[cb], %[nls], %[ca]\n\t"
+                             "v_add_u32 %[a], %[sb], %[a]\n\t"
+                             "s_mov_b64 %[sv], exec\n\t"
+                             "s_mov_b64 exec, %[m]\n\t"
+                             "ds_write_b128 %[a], %[d0]\n\t"
+                             "ds_write_b128 %[a], %[d1] offset:16\n\t"
+                             "ds_write_b128 %[a], %[d2] offset:32\n\t"
+                             "ds_write_b128 %[a], %[d3] offset:48\n\t"
+                             "s_mov_b64 exec, %[sv]"
+                             : [a] "=&v"(addr), [sv] "=&s"(sv)
+                             : [cb] "v"(peak_cb), [nls] "s"(-ls), [ca] "v"(peak_ca), [sb] "s"(sbase), [m] "s"(wmask), [d0] "v"(d0),
+                               [d1] "v"(d1), [d2] "v"(d2), [d3] "v"(d3)
+                             : "memory");
+            }
+#else
+            if (((wmask >> lane) & 1) && !(dbg & 512)) {
+                float4* hp = reinterpret_cast<float4*>(smem + sbase + peak_ca - peak_cb * ls);
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4)
                     hp[q4] = make_float4(mag[4 * q4], mag[4 * q4 + 1], mag[4 * q4 + 2], mag[4 * q4 + 3]);
             }
+#endif
             if (lane == 0) {
                 const u32x2 rec = {(unsigned)wmaxi, (unsigned)ls};
                 *reinterpret_cast<u32x2*>(red + rb * 8 + wave) = rec;
@@ -793,7 +838,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_win(const void* __restrict__ iq
             *reinterpret_cast<u32x4*>(red + rb * 8 + wave) = rec;
             if (wave == 0) oidx[rb] = out_idx;
         }
-#endif   // RMX_KWIN_PEAK1
+#endif   // RMX_KWIN_PEAK2
         ++npend;
         ++npair;
     };

@@ -1,10 +1,10 @@
 #!/bin/bash
 # GPU box: SQ counters of every kernel variant in tools/probe/kwin_bench (separate --pmc passes, short runs)
 set -o pipefail
-out=$PWD/gpurun_out/pmc_kwb
+out=$PWD/gpurun_out/${KWB_OUT:-pmc_kwb}
 rm -rf "$out"; mkdir -p "$out"
 export TMPDIR=/tmp
-BIN=$PWD/tools/probe/kwin_bench
+BIN=${KWB_BIN:-$PWD/tools/probe/kwin_bench}   # KWB_BIN=...: another build of the harness (tools/probe/kwb_*)
 cd /tmp
 [ -f $out/../counters.txt ] || rocprofv3 -L > $out/../counters.txt 2>&1
 i=0
