@@ -235,21 +235,27 @@ def recorded_traffic(config):
         f"digest {now}; recorded by tools/profile.sh, not measured in this run)")
 
 
-def recorded_counters(launch_ms):
-    """SQ / LDS / L2 counters per launch of the fused kernel from profiles/pmc_latest.json (tools/profile.sh passes, same
-    digest rule as the traffic figure) as the utilisation ratios SURVEY.md section 8d asks for beside the HBM fraction."""
-    pj = os.path.join(ROOT, "profiles", "pmc_latest.json")
-    if not os.path.exists(pj):
-        return None
-    try:
-        d = json.load(open(pj))
-    except Exception:
-        return None
-    if d.get("source_digest") != source_digest():
-        return {"stale": f"profiles/pmc_latest.json (tag {d.get('tag')}) was recorded on other sources; re-run tools/profile.sh"}
-    c = d["counters"]
+def recorded_counters(launch_ms, live=None):
+    """SQ / LDS / L2 counters per launch of the fused kernel -- measured in this run (`live`: measure_pmc_in_run, the SQ
+    set only) or from profiles/pmc_latest.json (tools/profile.sh passes, same digest rule as the traffic figure) -- as the
+    utilisation ratios SURVEY.md section 8d asks for beside the HBM fraction."""
+    if live and live.get("counters", {}).get("SQ_WAVE_CYCLES"):
+        c = live["counters"]
+        src = "measured in this run: rocprofv3 --pmc child pass of bench.py --profile, per launch of k_win"
+    else:
+        pj = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if not os.path.exists(pj):
+            return None
+        try:
+            d = json.load(open(pj))
+        except Exception:
+            return None
+        if d.get("source_digest") != source_digest():
+            return {"stale": f"profiles/pmc_latest.json (tag {d.get('tag')}) was recorded on other sources; re-run tools/profile.sh"}
+        c = d["counters"]
+        src = f"profiles/pmc_latest.json (tag {d.get('tag')}): rocprofv3 --pmc passes of bench.py --profile, per launch of {d.get('kernel')}"
     wc = c.get("SQ_WAVE_CYCLES") or 0.0
-    out = {"source": f"profiles/pmc_latest.json (tag {d.get('tag')}): rocprofv3 --pmc passes of bench.py --profile, per launch of {d.get('kernel')}",
+    out = {"source": src,
            "valu_wave_instructions": c.get("SQ_INSTS_VALU"), "lds_wave_instructions": c.get("SQ_INSTS_LDS"),
            "salu_wave_instructions": c.get("SQ_INSTS_SALU")}
     if wc:
@@ -270,28 +276,118 @@ def recorded_counters(launch_ms):
     return out
 
 
+PMC_SETS = {
+    # separate rocprofv3 --pmc passes, as MI355X_MICROARCH.md (HBM / rocprofv3 section) prescribes: FETCH_SIZE and WRITE_SIZE
+    # never share a pass with each other or with the SQ counters
+    "FETCH_SIZE": ["FETCH_SIZE"],
+    "WRITE_SIZE": ["WRITE_SIZE"],
+    "SQ": ["SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_LDS",
+           "SQ_INSTS_LDS", "SQ_INSTS_SALU"],
+}
+
+
+def parse_pmc_csv(path, kernel_sub="k_win"):
+    """{counter: mean per full-size launch} of the kernels whose name contains kernel_sub in one rocprofv3
+    counter_collection.csv: launches of the largest grid only, and of those the ones at least half as long as the
+    longer quarter's shortest (bench.py --profile also runs a 32-window parity leg through the same kernel)."""
+    import collections
+    import csv
+    rows = [r for r in csv.DictReader(open(path)) if kernel_sub in r["Kernel_Name"]]
+    if not rows:
+        return {}
+    gmax = max(int(r["Grid_Size"]) for r in rows)
+    rows = [r for r in rows if int(r["Grid_Size"]) == gmax]
+    acc = collections.defaultdict(list)
+    for r in rows:
+        acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    out = {k: sum(v) / len(v) for k, v in acc.items()}
+    out["launches_sampled"] = len(next(iter(acc.values())))
+    return out
+
+
+def measure_pmc_in_run(budget_s=150.0, steps=8, warmup=3):
+    """HBM traffic and SQ counters of the headline kernel measured IN THIS RUN (the figures copied from
+    profiles/*.json were a builder's claim): three child processes `rocprofv3 --pmc <one set> -- python3 bench.py
+    --profile` (FETCH_SIZE, WRITE_SIZE and the SQ set each in a pass of their own, no trace domain beside them), started
+    before this process has touched the GPU, each under a timeout.  Returns {"counters": {...per launch...},
+    "hbm_bytes_per_launch": (2 FETCH_SIZE + WRITE_SIZE) KiB (gfx950 counts 64 B per 128-B request of a wide stream:
+    MI355X_MICROARCH.md), ...} or {"error": why} -- the caller then falls back to the recorded files."""
+    import glob
+    import shutil
+    import tempfile
+    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rp):
+        return {"error": "rocprofv3 not found"}
+    t_start = time.perf_counter()
+    tmp = tempfile.mkdtemp(prefix="rmx_pmc_", dir="/tmp")
+    env = dict(os.environ)
+    env["TMPDIR"] = "/tmp"
+    env["RMX_BENCH_CHILD"] = "1"
+    counters, notes = {}, []
+    try:
+        for name, cs in PMC_SETS.items():
+            left = budget_s - (time.perf_counter() - t_start)
+            if left < 20.0:
+                notes.append(f"{name}: skipped (time budget)")
+                continue
+            d = os.path.join(tmp, name)
+            cmd = [rp, "--pmc"] + cs + ["-f", "csv", "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
+                                        "--profile", "--steps", str(steps), "--warmup", str(warmup)]
+            try:
+                r = subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True, timeout=min(left, 90.0))
+            except subprocess.TimeoutExpired:
+                notes.append(f"{name}: timed out")
+                continue
+            if r.returncode != 0:
+                notes.append(f"{name}: rocprofv3 exit {r.returncode}: {(r.stderr or r.stdout)[-200:]}")
+                continue
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                notes.append(f"{name}: no counter_collection.csv")
+                continue
+            got = parse_pmc_csv(files[0])
+            n = got.pop("launches_sampled", 0)
+            counters.update(got)
+            notes.append(f"{name}: {n} full-size launches")
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    out = {"counters": counters, "passes": notes, "seconds": time.perf_counter() - t_start,
+           "method": "rocprofv3 --pmc, one counter set per child run of `bench.py --profile` (separate passes), per full-size launch of k_win"}
+    if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
+        out["hbm_bytes_per_launch"] = (2.0 * counters["FETCH_SIZE"] + counters["WRITE_SIZE"]) * 1024.0
+        out["note"] = "FETCH_SIZE (KiB) doubled per MI355X_MICROARCH.md: gfx950 counts 64 B per 128-B request; WRITE_SIZE (KiB) as counted"
+    elif not counters:
+        out["error"] = "; ".join(notes) or "no counters"
+    return out
+
+
 VALU_CLOCK_GHZ = 2.4        # MI355X_MICROARCH.md: max clock; a wave64 VALU instruction occupies its 32-wide SIMD for 2 cycles
 N_SIMDS = 256 * 4
 
 
-def recorded_valu(launch_ms):
+def recorded_valu(launch_ms, live=None):
     """`roofline.valu`: the fused kernel against the resource that actually binds it -- fp32 VALU issue.  Wave-instructions
-    per launch from profiles/pmc_latest.json (same digest rule as the traffic figure), their issue time at the data-sheet
-    rate of 2 cycles per wave64 instruction on each of the 1024 SIMDs at 2.4 GHz, and that time over this run's launch."""
-    pj = os.path.join(ROOT, "profiles", "pmc_latest.json")
-    try:
-        d = json.load(open(pj))
-    except Exception:
-        return None
-    if d.get("source_digest") != source_digest():
-        return {"stale": f"profiles/pmc_latest.json (tag {d.get('tag')}) was recorded on other sources; re-run tools/profile.sh"}
-    n = d.get("counters", {}).get("SQ_INSTS_VALU")
+    per launch measured in this run (`live`: measure_pmc_in_run) or, failing that, from profiles/pmc_latest.json (same
+    digest rule as the traffic figure), their issue time at the data-sheet rate of 2 cycles per wave64 instruction on each
+    of the 1024 SIMDs at 2.4 GHz, and that time over this run's launch."""
+    n, src = None, None
+    if live and live.get("counters", {}).get("SQ_INSTS_VALU"):
+        n, src = live["counters"]["SQ_INSTS_VALU"], "measured in this run (rocprofv3 --pmc child pass, SQ_INSTS_VALU per launch of k_win)"
+    else:
+        pj = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        try:
+            d = json.load(open(pj))
+        except Exception:
+            return None
+        if d.get("source_digest") != source_digest():
+            return {"stale": f"profiles/pmc_latest.json (tag {d.get('tag')}) was recorded on other sources; re-run tools/profile.sh"}
+        n = d.get("counters", {}).get("SQ_INSTS_VALU")
+        src = f"profiles/pmc_latest.json (tag {d.get('tag')}, SQ_INSTS_VALU per launch of {d.get('kernel')})"
     if not n or not launch_ms:
         return None
     issue_ms = n * 2.0 / (N_SIMDS * VALU_CLOCK_GHZ * 1e9) * 1e3
     return {"wave_instructions": n, "issue_ms_at_2cyc": issue_ms, "frac_of_launch": issue_ms / launch_ms,
-            "clock_ghz_assumed": VALU_CLOCK_GHZ, "simds": N_SIMDS,
-            "source": f"profiles/pmc_latest.json (tag {d.get('tag')}, SQ_INSTS_VALU per launch of {d.get('kernel')})"}
+            "clock_ghz_assumed": VALU_CLOCK_GHZ, "simds": N_SIMDS, "source": src}
 
 
 class Shape:
@@ -499,6 +595,9 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true", help="skip the other four BASELINE shapes (profiling runs)")
     ap.add_argument("--no-single-group", action="store_true", help="skip the one-window latency probe (profiling runs)")
     ap.add_argument("--no-projection", action="store_true", help="skip the one-GPU strong-scaling projection (profiling runs)")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="do not measure HBM traffic / SQ counters in this run (three rocprofv3 --pmc child runs, ~30 s); "
+                         "the figures recorded under profiles/ are used instead when their source digest matches")
     ap.add_argument("--no-host-path", action="store_true", help="skip the host-pointer legs (profiling runs)")
     ap.add_argument("--profile", action="store_true",
                     help="the timed path and its parity only: --no-other-configs --no-projection --no-single-group --no-host-path --no-cpu-baseline")
@@ -510,6 +609,7 @@ def main():
         ap.error("--gpus must be >= 1")
     if args.profile:
         args.no_other_configs = args.no_projection = args.no_single_group = args.no_host_path = args.no_cpu_baseline = True
+        args.no_pmc = True
 
     env_world = os.environ.get("WORLD_SIZE")
     if args.gpus > 1 and env_world is None:
@@ -521,6 +621,17 @@ def main():
         sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    # counters of the headline kernel, measured by child processes BEFORE this process touches the GPU (N = 1, cfg3 only)
+    live_pmc = None
+    if (world == 1 and rank == 0 and args.config == "cfg3" and not args.no_pmc and not args.launch_check
+            and os.environ.get("RMX_BENCH_CHILD") != "1" and args.buoys is None and args.windows is None):
+        import __graft_entry__ as ge0
+        ge0.build()                       # the children must not each compile the library
+        try:
+            live_pmc = measure_pmc_in_run()
+        except Exception as e:            # never let the measurement take the line with it
+            live_pmc = {"error": f"{type(e).__name__}: {e}"}
 
     import numpy as np
     import torch
@@ -772,6 +883,12 @@ def main():
         alg_bytes_per_launch = alg_bytes_per_step_gpu / launches_per_step
         achieved = alg_bytes_per_launch / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
         traffic, traffic_src = recorded_traffic(args.config)
+        if live_pmc and live_pmc.get("hbm_bytes_per_launch"):
+            traffic = live_pmc["hbm_bytes_per_launch"]
+            traffic_src = (f"measured in this run: {live_pmc['method']}; {'; '.join(live_pmc['passes'])}; {live_pmc['note']} "
+                           f"({live_pmc['seconds']:.0f} s)")
+        elif live_pmc:
+            traffic_src = (traffic_src or "no recorded figure") + f" [in-run measurement failed: {live_pmc.get('error') or live_pmc.get('passes')}]"
         ingest = W_total * B * N / (ms_per_step * 1e-3)       # input samples taken in per second, all ranks
         line = {
             "metric": "IQ samples cross-correlated per second" + (" (pair-window-Doppler-bin samples)" if caf else ""),
@@ -801,8 +918,8 @@ def main():
                          "pair_kernel_ms_per_step": pair_ms / n_meas,
                          "whole_path_frac": alg_bytes_per_step_gpu / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "whole_path_frac_sustained": alg_bytes_per_step_gpu / (ms_per_step_sustained * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "valu": recorded_valu(launch_ms) if fused else None,
-                         "counters": recorded_counters(launch_ms) if fused else None,
+                         "valu": recorded_valu(launch_ms, live_pmc) if fused else None,
+                         "counters": recorded_counters(launch_ms, live_pmc) if fused else None,
                          "fp32_valu_and_lds": "DESIGN.md section 7: the fused kernel is bound by fp32 VALU issue (70 % of the launch "
                                               "with DPP / compare forms weighted), not by HBM"},
             "ingest_samples_per_s": ingest,

@@ -50,7 +50,7 @@ inline const std::vector<OptionSpec>& option_specs() {
         {"gen_chunk", 1, 4096, "generic path: at most n windows per chunk of kernel launches"},
         {"rows_tpr", 1, 1024, "four-step: threads per row (selects the run-time-length row kernels)"},
         {"cols_threads", 64, 1024, "four-step: threads per column tile"},
-        {"col_logt", 3, 4, "four-step: log2 columns per tile"},
+        {"col_logt", 3, 5, "four-step: log2 columns per tile"},
 #ifdef RMX_EXPERIMENTS
         {"kwin8k", 0, 1, "1: N = 8192 through k_win8k (the bin-parity halves on the fused N = 4096 network; -DRMX_EXPERIMENTS builds only)"},
         {"pk", 0, 1, "1: k_winp (packed fp32 build of the fused kernel; -DRMX_EXPERIMENTS builds only)"},

@@ -886,6 +886,11 @@ static size_t gen_rows_lds(const rmx_ctx* c, int R) {   // rows + per-row twiddl
 static const void* cols_inv_fn(int l1, int lt, int thr) {
     using namespace gen;
     if (lt == 3) return (const void*)g_cols_inv<3>;
+    if (lt == 5) {          // 32-column tiles (256-byte row segments): option col_logt = 5, an A/B switch (VERDICT r04 #3a)
+        if (thr == cols_threads(l1, 5) && l1 == 8) return (const void*)g_cols_inv<5, 8>;
+        if (thr == cols_threads(l1, 5) && l1 == 9) return (const void*)g_cols_inv<5, 9>;
+        return (const void*)g_cols_inv<5>;
+    }
     if (thr == cols_threads(l1, 4)) switch (l1) {
         case 5: return (const void*)g_cols_inv<4, 5>;
         case 6: return (const void*)g_cols_inv<4, 6>;
@@ -900,6 +905,11 @@ template <bool U8>
 static const void* cols_fwd_fn(int l1, int lt, int thr) {
     using namespace gen;
     if (lt == 3) return (const void*)g_cols_fwd<U8, 3>;
+    if (lt == 5) {
+        if (thr == cols_threads(l1, 5) && l1 == 8) return (const void*)g_cols_fwd<U8, 5, 8>;
+        if (thr == cols_threads(l1, 5) && l1 == 9) return (const void*)g_cols_fwd<U8, 5, 9>;
+        return (const void*)g_cols_fwd<U8, 5>;
+    }
     if (thr == cols_threads(l1, 4)) switch (l1) {
         case 5: return (const void*)g_cols_fwd<U8, 4, 5>;
         case 6: return (const void*)g_cols_fwd<U8, 4, 6>;

@@ -139,3 +139,21 @@ def test_recorded_valu_fraction(tmp_path, monkeypatch):
     (prof / "pmc_latest.json").write_text(json.dumps({"kernel": "k_win", "tag": "old", "source_digest": "b" * 16,
                                                       "counters": {"SQ_INSTS_VALU": 9.03e8}}))
     assert "stale" in bench.recorded_valu(1.685)
+
+
+def test_parse_pmc_csv_keeps_full_size_launches(tmp_path):
+    """measure_pmc_in_run's parser: counters per launch of k_win, full-size launches only (the parity leg of the child
+    run launches the same kernel on a smaller grid); other kernels ignored."""
+    import bench
+    p = tmp_path / "pmc_counter_collection.csv"
+    rows = ["Correlation_Id,Dispatch_Id,Agent_Id,Queue_Id,Process_Id,Thread_Id,Grid_Size,Kernel_Id,Kernel_Name,Workgroup_Size,LDS_Block_Size,Scratch_Size,VGPR_Count,Accum_VGPR_Count,SGPR_Count,Counter_Name,Counter_Value,Start_Timestamp,End_Timestamp"]
+    def row(d, grid, name, cn, cv):
+        return f"{d},{d},1,1,1,1,{grid},7,\"{name}\",512,159008,0,232,0,112,{cn},{cv},0,0"
+    for d, v in ((1, 1000.0), (2, 1100.0), (3, 900.0)):
+        rows.append(row(d, 131072, "void rmx::k_win<false>(void const*, HIP_vector_type<float, 4u>*)", "FETCH_SIZE", v))
+    rows.append(row(4, 16384, "void rmx::k_win<false>(void const*, HIP_vector_type<float, 4u>*)", "FETCH_SIZE", 5.0))   # parity leg
+    rows.append(row(5, 131072, "at::native::vectorized_elementwise_kernel<4>", "FETCH_SIZE", 1e9))
+    p.write_text("\n".join(rows) + "\n")
+    got = bench.parse_pmc_csv(str(p))
+    assert got == {"FETCH_SIZE": 1000.0, "launches_sampled": 3}
+    assert bench.parse_pmc_csv(str(p), kernel_sub="no_such_kernel") == {}
