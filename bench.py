@@ -323,6 +323,7 @@ def measure_pmc_in_run(budget_s=150.0, steps=8, warmup=3):
     env = dict(os.environ)
     env["TMPDIR"] = "/tmp"
     env["RMX_BENCH_CHILD"] = "1"
+    env["RMX_BENCH_PREWARM"] = "0"       # the children need launches to count, not a settled clock
     counters, notes = {}, []
     try:
         for name, cs in PMC_SETS.items():

@@ -34,8 +34,9 @@
 #endif
 #include "generic_path.hpp"
 #include "win_eo.hpp"
+#include "kwin8k.hpp"                           // N = 8192 on k_win's network, one anchor half resident in LDS (k_win8kl)
 #ifdef RMX_EXPERIMENTS
-#include "../../tools/experiments/kwin8k.hpp"   // N = 8192 on k_win's network: parity-green, not faster (LABNOTES.md R4.6)
+#include "../../tools/experiments/kwin8k.hpp"   // its two predecessors: parity-green, not faster (LABNOTES.md R4.6)
 #endif
 #include "detect_path.hpp"
 
@@ -680,7 +681,8 @@ struct rmx_ctx {
     float4* g_ws_scratch = nullptr;
     float2* g_tw_win = nullptr;            // W_L half table of that kernel
     float2* g_tw_l = nullptr;              // g_win_eo15 (N = 16384): W_32768^i, i < 1024
-    bool g_k8 = false;                     // N = 8192: k_win8k (kwin8k.hpp) instead of g_win_scr14 for batches that fill the chip
+    bool g_k8 = false;                     // N = 8192: k_win8kl (kwin8k.hpp) instead of g_win_scr14 for batches that fill the chip
+    int g_k8_kind = 1;                     // 1 = k_win8kl (LDS-resident anchor half), 2 = k_win8k (experiments build)
     float4* g_k8_tw1 = nullptr;            // its TW1 tables (both halves)
     float2* g_k8_tw2 = nullptr;            // k_win's TW2 table
     const void* g_cols_inv_fn = nullptr;
@@ -1154,10 +1156,11 @@ static int generic_init(rmx_ctx* c) {
         const size_t sbytes = (size_t)grid * c->g_ws_upw * c->n_buoys * L * 8;
         RMX_HIP(c, hipMalloc((void**)&c->g_ws_scratch, sbytes));
         c->scratch_bytes += sbytes;
-#ifdef RMX_EXPERIMENTS
-        // N = 8192: the two bin-parity halves on the fused N = 4096 kernel's network (k_win8k), same scratch size
-        // (B x 2 x 64 KiB per persistent workgroup), one workgroup per CU; experiments build, option kwin8k = 1
-        if (c->g_logL == 14 && c->knobs.get_or("kwin8k", 0) != 0) {
+        // N = 8192: the two bin-parity halves on the fused N = 4096 kernel's network (kwin8k.hpp), same scratch size
+        // (B x 2 x 64 KiB per persistent workgroup), one workgroup per CU.  Option kwin8k: 1 (default) = k_win8kl, one anchor
+        // half resident in LDS -- 0.60 against g_win_scr14's 0.73 ms at 8 buoys x 512 windows, 1.10 against 1.42 at 16 x 256,
+        // 0.27 against 0.285 at 3 x 1024 --; 0 = g_win_scr14; 2 = k_win8k (no resident anchor: -DRMX_EXPERIMENTS builds only)
+        if (c->g_logL == 14 && c->knobs.get_or("kwin8k", 1) != 0) {
             std::vector<float4> t1;
             std::vector<float4> t1_4096;
             std::vector<float2> t2;
@@ -1168,11 +1171,17 @@ static int generic_init(rmx_ctx* c) {
             RMX_HIP(c, hipMalloc((void**)&c->g_k8_tw2, t2.size() * sizeof(float2)));
             RMX_HIP(c, hipMemcpy(c->g_k8_tw2, t2.data(), t2.size() * sizeof(float2), hipMemcpyHostToDevice));
             c->scratch_bytes += t1.size() * sizeof(float4) + t2.size() * sizeof(float2);
+            RMX_HIP(c, hipFuncSetAttribute((const void*)k8::k_win8kl<false>, hipFuncAttributeMaxDynamicSharedMemorySize, k8::kLdsLBytes));
+            RMX_HIP(c, hipFuncSetAttribute((const void*)k8::k_win8kl<true>, hipFuncAttributeMaxDynamicSharedMemorySize, k8::kLdsLBytes));
+            c->g_k8 = c->g_ws_upw == 1 && grid <= c->n_cus;      // (its grid is the scratch's: one window slot per workgroup)
+            c->g_k8_kind = (int)c->knobs.get_or("kwin8k", 1);
+#ifdef RMX_EXPERIMENTS
             RMX_HIP(c, hipFuncSetAttribute((const void*)k8::k_win8k<false>, hipFuncAttributeMaxDynamicSharedMemorySize, k8::kLds8Bytes));
             RMX_HIP(c, hipFuncSetAttribute((const void*)k8::k_win8k<true>, hipFuncAttributeMaxDynamicSharedMemorySize, k8::kLds8Bytes));
-            c->g_k8 = c->g_ws_upw == 1 && grid <= c->n_cus;      // (its grid is the scratch's: one window slot per workgroup)
-        }
+#else
+            if (c->g_k8_kind == 2) return fail(c, RMX_E_UNSUPPORTED, "option kwin8k = 2 (k_win8k) exists only in a -DRMX_EXPERIMENTS build");
 #endif
+        }
     }
     // windows per chunk (host_plan.hpp: spectra + products under 32 GiB of the 288, "gen_chunk" caps it for experiments)
     const long chunk = host::generic_chunk_windows(c->n_buoys, L, c->max_windows, 32L << 30, c->knobs.get_or("gen_chunk", 0));
@@ -1425,26 +1434,36 @@ static int generic_batch(rmx_ctx* c, const void* d_iq, int n_windows, int n_pair
         const gen::GPair* a_pairs = c->g_pairs;
         long grid = ((long)n_windows + c->g_ws_upw - 1) / c->g_ws_upw;
         if (grid > c->g_ws_grid) grid = c->g_ws_grid;
-#ifdef RMX_EXPERIMENTS
         const bool def_list = c->plan_all_pairs && n_pairs == c->n_buoys * (c->n_buoys - 1) / 2;
         if (c->g_k8 && (def_list || n_pairs <= k8::kMaxPairs8)) {   // N = 8192 on k_win's network (kwin8k.hpp)
             const float out_scale = std::ldexp(1.0f, 3 * kTw1ScaleLog2 - 14);
             const k8::Pair2* prs = def_list ? nullptr : reinterpret_cast<const k8::Pair2*>(c->g_pairs);
             const int stag = (int)c->knobs.get_or("stag", 1);
             RMX_TM_BEGIN(c);
+#ifdef RMX_EXPERIMENTS
+            if (c->g_k8_kind == 2) {
+                if (u8)
+                    hipLaunchKernelGGL(k8::k_win8k<true>, dim3((unsigned)grid), dim3(kThreads), k8::kLds8Bytes, c->stream, d_iq,
+                                       c->g_ws_scratch, c->g_k8_tw1, c->g_k8_tw2, c->n_buoys, prs, n_pairs, 0L, out_scale, d_lag,
+                                       d_frac, d_peak, n_windows, stag);
+                else
+                    hipLaunchKernelGGL(k8::k_win8k<false>, dim3((unsigned)grid), dim3(kThreads), k8::kLds8Bytes, c->stream, d_iq,
+                                       c->g_ws_scratch, c->g_k8_tw1, c->g_k8_tw2, c->n_buoys, prs, n_pairs, 0L, out_scale, d_lag,
+                                       d_frac, d_peak, n_windows, stag);
+            } else
+#endif
             if (u8)
-                hipLaunchKernelGGL(k8::k_win8k<true>, dim3((unsigned)grid), dim3(kThreads), k8::kLds8Bytes, c->stream, d_iq,
+                hipLaunchKernelGGL(k8::k_win8kl<true>, dim3((unsigned)grid), dim3(kThreads), k8::kLdsLBytes, c->stream, d_iq,
                                    c->g_ws_scratch, c->g_k8_tw1, c->g_k8_tw2, c->n_buoys, prs, n_pairs, 0L, out_scale, d_lag,
                                    d_frac, d_peak, n_windows, stag);
             else
-                hipLaunchKernelGGL(k8::k_win8k<false>, dim3((unsigned)grid), dim3(kThreads), k8::kLds8Bytes, c->stream, d_iq,
+                hipLaunchKernelGGL(k8::k_win8kl<false>, dim3((unsigned)grid), dim3(kThreads), k8::kLdsLBytes, c->stream, d_iq,
                                    c->g_ws_scratch, c->g_k8_tw1, c->g_k8_tw2, c->n_buoys, prs, n_pairs, 0L, out_scale, d_lag,
                                    d_frac, d_peak, n_windows, stag);
             RMX_HIP(c, hipGetLastError());
             RMX_TM_END(c, kTkWindow);
             return RMX_OK;
         }
-#endif
         if (logL == 15) {                          // g_win_eo15: one more table
             const float2* a_twl = c->g_tw_l;
             void* args[] = {&a_iq, &a_scr, &a_tw, &a_twl, &a_nb, &a_nw, &a_first, &a_fs, &a_os, &a_pairs, &a_np, &d_lag, &d_frac, &d_peak};

@@ -808,11 +808,23 @@ def test_whole_window_scratch_kernel_by_length(xc, N, B, opts):
     assert np.array_equal(li, l8) and np.array_equal(lf, f8) and np.array_equal(pk, p8)
     oi, of_, op = orc.xcorr_batch_literal(iq[sub], custom)
     _assert_parity(ci, cf, cp, oi, of_, op)
-    if N == 8192 and B in (3, 8):               # L = 16384 has two builds: 512 threads x two butterflies (default), 1024 x one
-        opts("wscr14", 0)
-        with xc.XcorrEngine(B, N, W) as eng:
-            ai, af, ap = eng.correlate(iq)
-        assert np.array_equal(ai, li) and np.all(np.abs(af - lf) <= TOL) and np.allclose(ap, pk, rtol=1e-5)
+    if N == 8192:
+        # three builds of this length: k_win8kl (the default above: the bin-parity halves on the fused N = 4096 kernel's
+        # network, one anchor half resident in LDS -- kwin8k.hpp), g_win_scr14 (option kwin8k = 0: 512 threads x two
+        # butterflies per pass) and g_win_scr<14> (+ wscr14 = 0: 1024 threads x one)
+        for more in ((("kwin8k", 0),), (("kwin8k", 0), ("wscr14", 0))) if B in (3, 8) else ((("kwin8k", 0),),):
+            xc.clear_default_options()
+            opts("wscr", 2)
+            for k, v in more:
+                opts(k, v)
+            with xc.XcorrEngine(B, N, W) as eng:
+                ai, af, ap = eng.correlate(iq)
+                a8 = eng.correlate(raw)
+                qi, qf, qp = eng.correlate(iq[sub], custom)
+            assert np.array_equal(ai, li) and np.all(np.abs(af - lf) <= TOL) and np.allclose(ap, pk, rtol=1e-5), more
+            assert all(np.array_equal(x, y) for x, y in zip((ai, af, ap), a8))
+            _assert_parity(qi, qf, qp, oi, of_, op)
+        xc.clear_default_options()
     opts("wscr", 0)
     opts("wfused", 0)
     with xc.XcorrEngine(B, N, W) as eng:

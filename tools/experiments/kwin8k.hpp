@@ -1,143 +1,13 @@
-// kwin8k.hpp -- k_win8k: the reference's streaming capture length N = 8192 (iq_stream_client.py:459) on the machinery
-// of the fused N = 4096 kernel (kwin.hpp / fft_r16.hpp), round 4.
-//
-// A window zero-padded from N = 8192 to L = 16384 splits by bin parity h into two 8192-point transforms,
-//     X[2 kappa + h] = FFT_8192( x[n] W_L^(h n) )[kappa],
-// and an 8192-point transform is what k_win's register / LDS network computes: two 4096-point sub-transforms p (bins
-// kappa = 2 kappa' + p) on 512 threads x 16 points, thread t = 2u + p, three radix-16 passes, the radix-2 between the
-// sub-transforms across lane pairs by DPP.  The only new pieces are the ends:
-//   forward  the first radix-2 is not free here (the half is not zero-padded): slot q of thread (u, p) starts from
-//            a + (-1)^p (-i)^h b,  a = x[n], b = x[n + 4096], n = u + 256 q,  twisted by W_L^((h + 2p) n): the per-slot part
-//            W_64^((h + 2p) q) as constants, the per-thread part W_L^((h + 2p) u) inside the TW1 table of half h;
-//   inverse  e_h = IFFT_8192(X_j,h conj X_i,h) comes out of k_win's inverse network (same tables: the network runs on
-//            (im, re)-swapped data, so every forward factor acts as its conjugate); e_0 waits in 32 registers while e_1
-//            is computed, then r[m] = e_0 + T, r[m + 8192] = e_0 - T with T = W_L^(-m) e_1 (the twist is half 1's own
-//            sub-transform twist; lanes p = 1 hold m = n + 4096 and take the extra factor +i), |.|^2 of both, and the
-//            peak search over the thread's 32 values.
-// STATUS (round 4): parity-green on its first run (tests/check_k8.py: oracle, custom pair lists, raw uint8), but NOT faster
-// than g_win_scr14 -- 0.70 against 0.73 ms at 8 buoys x 512 windows, 0.30 against 0.285 ms at 3 x 1024, 1.29 against 1.42 ms at
-// 16 x 256 -- because without a resident anchor its scratch traffic (7 TB/s through the memory-side cache) is the limit:
-// LABNOTES.md R4.6 has the ablations.  Compiled only with -DRMX_EXPERIMENTS (option kwin8k = 1 then selects it).
-// Per window: 2 B forward transforms, all stored (B x 128 KiB of the workgroup's scratch), then 2 P pair transforms;
-// no resident anchor (the halves alternate: both spectra of a transform are requested one transform ahead; measured
-// on k_win itself, an anchor re-requested for every pair costs 8 %: LABNOTES R4.6), the TW1 table of the other half is
-// re-requested behind its last use, the TW2 row comes from LDS (the 30 registers go to e_0).  Any pair list.
+// kwin8k.hpp (experiments) -- the first two versions of the N = 8192 kernel on the fused N = 4096 network, round 4: k_win8k
+// (no resident anchor) and k_win8ka (both anchor halves in registers, TW1 rebuilt from four powers).  Neither beat
+// g_win_scr14 (LABNOTES.md R4.6); round 5's third version, k_win8kl (one anchor half resident in LDS), does and lives in the
+// product: radio-mapper_amd/csrc/kwin8k.hpp, which also holds the helpers shared with these two (constants, twists, records).
+// Compiled only with -DRMX_EXPERIMENTS (option kwin8k = 2 then selects k_win8k; tools/probe/k8_bench.hip times all three).
 #pragma once
-#include <hip/hip_runtime.h>
-
-#include <cmath>
-#include <type_traits>
-#include <vector>
-
-#include "../../radio-mapper_amd/csrc/fft_r16.hpp"
-#include "../../radio-mapper_amd/csrc/kwin.hpp"
+#include "../../radio-mapper_amd/csrc/kwin8k.hpp"
 
 namespace rmx {
 namespace k8 {
-
-constexpr int kN8 = 8192;                 // window length
-constexpr int kSlots8 = 4, kBatch8 = 3;   // record ring / pairs per resolve (halo rows are 32 wide here)
-constexpr int kLds8Tw2 = 2 * kLdsWinImg;
-constexpr int kLds8Halo = kLds8Tw2 + kLdsTw2;                          // [slots][8 waves][4 rows][32] float
-constexpr int kLds8Red = kLds8Halo + kSlots8 * 8 * 4 * 32 * 4;        // [slots][8] float4
-constexpr int kLds8Oidx = kLds8Red + kSlots8 * 8 * 16;                // [slots] int
-constexpr int kLds8Pairs = kLds8Oidx + kSlots8 * 4;                    // custom pair list, at most kMaxPairs8 entries
-constexpr int kMaxPairs8 = 640;
-constexpr int kLds8Bytes = kLds8Pairs + kMaxPairs8 * 8;
-static_assert(kLds8Bytes <= 160 * 1024, "k_win8k LDS");
-
-struct Pair2 { int i, j; };               // same layout as gen::GPair
-
-__device__ __forceinline__ float2 w64(int e) {   // exp(-2 pi i e / 64)
-    constexpr float c[64] = {1.0f, 0.9951847195625305f, 0.9807852506637573f, 0.9569403529167175f, 0.9238795042037964f, 0.8819212913513184f, 0.8314695954322815f, 0.7730104327201843f, 0.7071067690849304f, 0.6343932747840881f, 0.5555702447891235f, 0.4713967442512512f, 0.3826834261417389f, 0.290284663438797f, 0.19509032368659973f, 0.0980171412229538f, 0.0f, -0.0980171412229538f, -0.19509032368659973f, -0.290284663438797f, -0.3826834261417389f, -0.4713967442512512f, -0.5555702447891235f, -0.6343932747840881f, -0.7071067690849304f, -0.7730104327201843f, -0.8314695954322815f, -0.8819212913513184f, -0.9238795042037964f, -0.9569403529167175f, -0.9807852506637573f, -0.9951847195625305f, -1.0f, -0.9951847195625305f, -0.9807852506637573f, -0.9569403529167175f, -0.9238795042037964f, -0.8819212913513184f, -0.8314695954322815f, -0.7730104327201843f, -0.7071067690849304f, -0.6343932747840881f, -0.5555702447891235f, -0.4713967442512512f, -0.3826834261417389f, -0.290284663438797f, -0.19509032368659973f, -0.0980171412229538f, 0.0f, 0.0980171412229538f, 0.19509032368659973f, 0.290284663438797f, 0.3826834261417389f, 0.4713967442512512f, 0.5555702447891235f, 0.6343932747840881f, 0.7071067690849304f, 0.7730104327201843f, 0.8314695954322815f, 0.8819212913513184f, 0.9238795042037964f, 0.9569403529167175f, 0.9807852506637573f, 0.9951847195625305f};
-    constexpr float s[64] = {0.0f, -0.0980171412229538f, -0.19509032368659973f, -0.290284663438797f, -0.3826834261417389f, -0.4713967442512512f, -0.5555702447891235f, -0.6343932747840881f, -0.7071067690849304f, -0.7730104327201843f, -0.8314695954322815f, -0.8819212913513184f, -0.9238795042037964f, -0.9569403529167175f, -0.9807852506637573f, -0.9951847195625305f, -1.0f, -0.9951847195625305f, -0.9807852506637573f, -0.9569403529167175f, -0.9238795042037964f, -0.8819212913513184f, -0.8314695954322815f, -0.7730104327201843f, -0.7071067690849304f, -0.6343932747840881f, -0.5555702447891235f, -0.4713967442512512f, -0.3826834261417389f, -0.290284663438797f, -0.19509032368659973f, -0.0980171412229538f, 0.0f, 0.0980171412229538f, 0.19509032368659973f, 0.290284663438797f, 0.3826834261417389f, 0.4713967442512512f, 0.5555702447891235f, 0.6343932747840881f, 0.7071067690849304f, 0.7730104327201843f, 0.8314695954322815f, 0.8819212913513184f, 0.9238795042037964f, 0.9569403529167175f, 0.9807852506637573f, 0.9951847195625305f, 1.0f, 0.9951847195625305f, 0.9807852506637573f, 0.9569403529167175f, 0.9238795042037964f, 0.8819212913513184f, 0.8314695954322815f, 0.7730104327201843f, 0.7071067690849304f, 0.6343932747840881f, 0.5555702447891235f, 0.4713967442512512f, 0.3826834261417389f, 0.290284663438797f, 0.19509032368659973f, 0.0980171412229538f};
-    return make_float2(c[e & 63], s[e & 63]);
-}
-
-// v[q] *= W_64^(R q), q = 1..15, in place (constants as scalar operands: the forms of mul_w32_odd in kwin.hpp)
-template <int R>
-__device__ __forceinline__ void mul_twist(float2 (&v)[16]) {
-#pragma unroll
-    for (int q = 1; q < 4; ++q) {
-        const float2 w = w64(R * q);
-        float x = v[q].x, y = v[q].y;
-        cmul_inplace(x, y, w.x, w.y);
-        v[q].x = x;
-        v[q].y = y;
-    }
-#pragma unroll
-    for (int q = 4; q < 16; q += 4) {
-        float x0 = v[q].x, y0 = v[q].y, x1 = v[q + 1].x, y1 = v[q + 1].y;
-        float x2 = v[q + 2].x, y2 = v[q + 2].y, x3 = v[q + 3].x, y3 = v[q + 3].y;
-        cmul4_inplace(x0, y0, x1, y1, x2, y2, x3, y3, w64(R * q), w64(R * (q + 1)), w64(R * (q + 2)), w64(R * (q + 3)));
-        v[q].x = x0; v[q].y = y0; v[q + 1].x = x1; v[q + 1].y = y1;
-        v[q + 2].x = x2; v[q + 2].y = y2; v[q + 3].x = x3; v[q + 3].y = y3;
-    }
-}
-
-// 'full' index kk (0 .. 2N-2) -> owner thread, value slot sg = 16 (1 - j) + q  (j = 1: r[m + 8192], the negative lags)
-__device__ __forceinline__ void k_to_owner8(int kk, int& tt, int& sg) {
-    const int j = kk < kN8 - 1 ? 1 : 0;
-    const int m = j ? kk + 1 : kk - (kN8 - 1);        // = n + 4096 p, 0 .. 8191
-    const int pp = m >> 12, n = m & 4095;
-    tt = 2 * (n & 255) + pp;
-    sg = (j ? 0 : 16) + (n >> 8);
-}
-
-// resolve_batch of kwin.hpp for this kernel's records: lane = 8 g + r looks at wave r's record of the g-th pending pair
-__device__ __forceinline__ void resolve_batch8(int lane, const float4* red, const float* halo, const int* oidx, int first,
-                                               int cnt, long obase, float out_scale, int* __restrict__ lag_int,
-                                               float* __restrict__ lag_frac, float* __restrict__ peak) {
-    const int g = lane >> 3, r = lane & 7;
-    const bool act = g < cnt;
-    const int slot = (first + (act ? g : 0)) & (kSlots8 - 1);
-    const float* rf = reinterpret_cast<const float*>(red) + 4 * (slot * 8 + r);
-    const int* ri = reinterpret_cast<const int*>(rf);
-    const float ex = act ? rf[0] : -3.0f;
-    const int k = act ? ri[1] : 0x7fffffff;
-    const float tm = rf[2], tp = rf[3];
-    const int out = oidx[slot];
-    float gmax = ex;
-    gmax = fmaxf(gmax, __builtin_bit_cast(float, dpp_i<0xB1>(__builtin_bit_cast(int, gmax))));
-    gmax = fmaxf(gmax, __builtin_bit_cast(float, dpp_i<0x4E>(__builtin_bit_cast(int, gmax))));
-    gmax = fmaxf(gmax, __builtin_bit_cast(float, dpp_i<0x141>(__builtin_bit_cast(int, gmax))));
-    int kstar = (ex == gmax) ? k : 0x7fffffff;
-    kstar = min(kstar, dpp_i<0xB1>(kstar));
-    kstar = min(kstar, dpp_i<0x4E>(kstar));
-    kstar = min(kstar, dpp_i<0x141>(kstar));
-    const bool win = act && ex == gmax && k == kstar;
-    auto halo_tap = [&](int kk) -> float {
-        kk = kk < 0 ? 0 : (kk > 2 * kN8 - 2 ? 2 * kN8 - 2 : kk);
-        int tt, sg;
-        k_to_owner8(kk, tt, sg);
-        const int ln = tt & 63;
-        const int row = ln < 2 ? ln : (ln >= 62 ? ln - 60 : 0);
-        return halo[(((slot * 8 + (tt >> 6)) * 4) + row) * 32 + sg];
-    };
-    const int kc = win ? k : (kN8 - 1);
-    const float hm = halo_tap(kc - 1), hp = halo_tap(kc + 1);
-    const float b = sqrtf(fmaxf(ex, 0.0f)) * out_scale;
-    const float a = sqrtf(tm >= 0.0f ? tm : hm) * out_scale;
-    const float c = sqrtf(tp >= 0.0f ? tp : hp) * out_scale;
-    const double den = (double)a - 2.0 * (double)b + (double)c;
-    float frac = 0.0f;
-    if (kc > 0 && kc < 2 * kN8 - 2 && den != 0.0) frac = (float)(0.5 * ((double)a - (double)c) / den);
-    if (win) {
-        lag_int[obase + out] = kc - (kN8 - 1);
-        lag_frac[obase + out] = frac;
-        peak[obase + out] = b;
-    }
-}
-
-// lowest slot of m[0..15] that equals t (16 if none): four select chains, descending so that lower slots win
-__device__ __forceinline__ int first_slot_eq(const float (&m)[16], float t) {
-    int qa = 16, qb = 16, qc = 16, qd = 16;
-    argsel4<12>(qa, qb, qc, qd, m[12], m[13], m[14], m[15], t);
-    argsel4<8>(qa, qb, qc, qd, m[8], m[9], m[10], m[11], t);
-    argsel4<4>(qa, qb, qc, qd, m[4], m[5], m[6], m[7], t);
-    argsel4<0>(qa, qb, qc, qd, m[0], m[1], m[2], m[3], t);
-    return min(min(qa, qb), min(qc, qd));
-}
 
 template <bool U8>
 __global__ __launch_bounds__(kThreads, 2) void k_win8k(const void* __restrict__ iq_v, float4* __restrict__ spec,
@@ -926,28 +796,6 @@ inline void build_tables8ka(std::vector<float4>& tws) {
         tws[t] = make_float4(w1.x, w1.y, w2.x, w2.y);
         tws[kThreads + t] = make_float4(w4.x, w4.y, w8.x, w8.y);
         tws[2 * kThreads + t] = make_float4(c[0].x, c[0].y, c[1].x, c[1].y);
-    }
-}
-
-// host: TW1 of both halves ([h][8][512] float4, register order as build_tables); TW2 is k_win's table
-inline void build_tables8k(std::vector<float4>& tw1) {
-    const double two_pi = 6.283185307179586476925286766559;
-    tw1.resize(2 * 8 * kThreads);
-    for (int h = 0; h < 2; ++h) {
-        std::vector<float2> t1(16 * kThreads);
-        for (int t = 0; t < kThreads; ++t) {
-            const int p = t & 1, u = t >> 1;
-            for (int k0 = 0; k0 < 16; ++k0) {
-                // W_4096^(u k0) * W_16384^((h + 2p) u), scaled by 2^-6 like k_win's table
-                const double ang = -two_pi * (double)((u * k0) % kM) / (double)kM - two_pi * (double)((h + 2 * p) * u) / 16384.0;
-                t1[k0 * kThreads + t] = make_float2((float)(std::cos(ang) * kTw1Scale), (float)(std::sin(ang) * kTw1Scale));
-            }
-        }
-        for (int j = 0; j < 8; ++j)
-            for (int t = 0; t < kThreads; ++t) {
-                const float2 a = t1[(2 * j) * kThreads + t], b = t1[(2 * j + 1) * kThreads + t];
-                tw1[(h * 8 + j) * kThreads + t] = make_float4(a.x, a.y, b.x, b.y);
-            }
     }
 }
 
