@@ -145,11 +145,11 @@ __device__ __forceinline__ int first_slot_eq(const float (&m)[16], float t) {
 // instead of 8).  The 64 KiB come out of the second exchange image, so a transform pays a second workgroup barrier (behind
 // its role-A reads) and the half-order staggering is gone.
 constexpr int kLdsLAnc = kLdsWinImg;                                   // [8][512] float4
-constexpr int kLdsLTw2 = kLdsLAnc + 8 * kThreads * 16;
-constexpr int kLdsLHalo = kLdsLTw2 + kLdsTw2;
+constexpr int kLdsLHalo = kLdsLAnc + 8 * kThreads * 16;
 constexpr int kLdsLRed = kLdsLHalo + kSlots8 * 8 * 4 * 32 * 4;
 constexpr int kLdsLOidx = kLdsLRed + kSlots8 * 8 * 16;
-constexpr int kLdsLPairs = kLdsLOidx + kSlots8 * 4;
+constexpr int kLdsLTw2 = kLdsLOidx + kSlots8 * 4;
+constexpr int kLdsLPairs = kLdsLTw2 + kLdsTw2;
 constexpr int kLdsLBytes = kLdsLPairs + kMaxPairs8 * 8;
 static_assert(kLdsLBytes <= 160 * 1024, "k_win8kl LDS");
 
@@ -280,70 +280,21 @@ __global__ __launch_bounds__(kThreads, 2) void k_win8kl(const void* __restrict__
         }
     };
 
-    // ---- phase 1: forward transforms, half-major (one TW1 table per half) ------------------------------------------
-    load_x(sa, 0, 0);
-    load_x(sb, 0, kN8 / 2);
-#ifdef K8_NO_FWD
-    if (n_win < 0)
-#endif
-    for (int h = 0; h < 2; ++h) {
-        load_tw1_half(h);
-        for (int b = 0; b < B; ++b) {
-            float2* img = img0;
-            cvt_x(sa);
-            cvt_x(sb);
-            float2 x[16];
-            if (h == 0) {
-#pragma unroll
-                for (int q = 0; q < 16; ++q) x[q] = make_float2(fmaf(sgn, sb.re[q], sa.re[q]), fmaf(sgn, sb.im[q], sa.im[q]));
-            } else {   // a + (-1)^p (-i) b
-#pragma unroll
-                for (int q = 0; q < 16; ++q) x[q] = make_float2(fmaf(sgn, sb.im[q], sa.re[q]), fmaf(-sgn, sb.re[q], sa.im[q]));
-            }
-            // (opaque from here on: the uint8 and the complex64 build must run the SAME arithmetic on these values)
-#pragma unroll
-            for (int q = 0; q < 16; q += 4)
-                asm volatile("" : "+v"(x[q].x), "+v"(x[q].y), "+v"(x[q + 1].x), "+v"(x[q + 1].y), "+v"(x[q + 2].x),
-                             "+v"(x[q + 2].y), "+v"(x[q + 3].x), "+v"(x[q + 3].y));
-            {   // the next transform's samples travel during this one (the sample registers are free behind the fold)
-                const int nb = b + 1 < B ? b + 1 : 0;
-#ifndef K8_NO_SAMPLE
-                if (b + 1 < B || h == 0) {
-                    load_x(sa, nb, 0);
-                    load_x(sb, nb, kN8 / 2);
-                }
-#endif
-            }
-            twist(x, h);
-            dft16(x);
-            mul_tw1(x, tw1);
-            __syncthreads();               // one image: every wave is through with the previous transform's wave-local reads
-            xchg_a2_write(img, x, t);
-            __syncthreads();
-            xchg_b2_read(img, x, t);
-            dft16(x);
-            const float4 r0 = tw2row[0], r1 = tw2row[1];
-            loc_write16(loc_m0, x);
-            wave_lds_order();
-            loc_read16(smem + loc_rd, x);
-            dft16_tw_row(x, tw2row, r0, r1);
-#ifndef K8_NO_STORE
-            store_spec(x, 2 * b + h);
-#endif
-            ++seq;
-        }
-    }
-
     // ---- phase 2: per pair, half 0 then half 1.  X_i's half 0 stays in `sa` and its half 1 in LDS (`anc`, thread-private
     // columns) for the anchor's run of pairs; only the streamed X_j,h is requested per transform.  One exchange image:
     // a second barrier per transform, right behind the role-A reads, frees the image for the next transform's stores.
     // H = the half as a compile-time constant.
-    auto pair_h1 = [&](auto hc, const C16& s, auto prefetch) __attribute__((always_inline)) {
+    auto pair_h1 = [&](auto hc, const auto& s, auto prefetch) __attribute__((always_inline)) {
         constexpr int H = decltype(hc)::value;
         float2* img = img0;
         float2 v[16];
+        if constexpr (std::is_same_v<std::remove_cv_t<std::remove_reference_t<decltype(s)>>, C16>) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) v[q] = make_float2(s.im[q], s.re[q]);
+            for (int q = 0; q < 16; ++q) v[q] = make_float2(s.im[q], s.re[q]);
+        } else {                           // (a spectrum that has just been computed: float2[16])
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v[q] = make_float2(s[q].y, s[q].x);
+        }
         if constexpr (H == 0) {
             dft16_tw_l1<false>(v, sa);
         } else {
@@ -388,11 +339,15 @@ __global__ __launch_bounds__(kThreads, 2) void k_win8kl(const void* __restrict__
         });
     };
     // everything of h2 behind the role-A reads (v = the 16 values read from the image)
-    auto pair_h2 = [&](auto hc, float2 (&v)[16], int out_idx) __attribute__((always_inline)) {
+    // late_tw1: request the other half's TW1 table at the END of the piece instead of behind this one's use (an A/B switch:
+    // in the interleaved first run the next buoy's samples are in flight as well; neither the spill count -- nine
+    // loop-invariant words, reloaded at four places -- nor the time improved with it)
+    auto pair_h2 = [&](auto hc, float2 (&v)[16], int out_idx, auto late_c) __attribute__((always_inline)) {
         constexpr int h = decltype(hc)::value;
+        constexpr bool late_tw1 = decltype(late_c)::value;
         dft16_tw<false>(v, tw1);
 #ifndef K8_NO_TW1
-        load_tw1_half(h ^ 1);                   // the other half's table travels while the rest of this piece runs
+        if constexpr (!late_tw1) load_tw1_half(h ^ 1);   // the other half's table travels while the rest of this piece runs
 #endif
 #ifndef K8_NO_TWIST
         twist(v, h);
@@ -404,6 +359,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_win8kl(const void* __restrict__
         if constexpr (h == 0) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) ev.set(q, v[q].x, v[q].y);
+#ifndef K8_NO_TW1
+            if constexpr (late_tw1) load_tw1_half(1);
+#endif
             return;
         } else {
 #ifdef K8_NO_PEAK
@@ -472,6 +430,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_win8kl(const void* __restrict__
         }
         ++npend;
         ++npair;
+#ifndef K8_NO_TW1
+        if constexpr (late_tw1) load_tw1_half(0);
+#endif
         }
     };
     auto all_parts = [&](C16& d, int sidx) __attribute__((always_inline)) {
@@ -486,10 +447,128 @@ __global__ __launch_bounds__(kThreads, 2) void k_win8kl(const void* __restrict__
         for (int j = 0; j < 8; ++j) anc[j * kThreads + t] = make_float4(ev.re[2 * j], ev.im[2 * j], ev.re[2 * j + 1], ev.im[2 * j + 1]);
     };
 
-    if (n_pairs > 0) {
+    // ---- forward transform of half h of buoy b from its samples in pa / pb (both halves of a buoy from ONE load: the 32
+    // eight-byte requests per thread -- lane pairs ask for the same sample -- are a visible part of a forward transform) into
+    // x, in registers.  `lead`: a barrier in front of the role-A stores (the transform before was a forward one too: some
+    // wave may still be at its wave-local reads; behind a pair transform its second barrier already says so).  `swap_tw1`:
+    // request the other half's TW1 table behind the use of this one (no pair transform of this half follows).  `nb` >= 0:
+    // request buoy nb's samples behind the fold (the sample registers are free behind a buoy's SECOND fold).
+    C16 pa, pb;
+    auto fwd_half = [&](auto hc, float2 (&x)[16], bool lead, bool swap_tw1, int nb) __attribute__((always_inline)) {
+        constexpr int h = decltype(hc)::value;
+        if constexpr (h == 0) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) x[q] = make_float2(fmaf(sgn, pb.re[q], pa.re[q]), fmaf(sgn, pb.im[q], pa.im[q]));
+        } else {   // a + (-1)^p (-i) b
+#pragma unroll
+            for (int q = 0; q < 16; ++q) x[q] = make_float2(fmaf(sgn, pb.im[q], pa.re[q]), fmaf(-sgn, pb.re[q], pa.im[q]));
+        }
+        // (opaque from here on: the uint8 and the complex64 build must run the SAME arithmetic on these values)
+#pragma unroll
+        for (int q = 0; q < 16; q += 4)
+            asm volatile("" : "+v"(x[q].x), "+v"(x[q].y), "+v"(x[q + 1].x), "+v"(x[q + 1].y), "+v"(x[q + 2].x),
+                         "+v"(x[q + 2].y), "+v"(x[q + 3].x), "+v"(x[q + 3].y));
+        if constexpr (h == 1) {
+            // The next buoy's samples travel from here on (the sample registers are free behind a buoy's second fold).
+            // UNCONDITIONAL requests (behind the last buoy: its own samples once more, into dead registers): hipcc merges a
+            // condition around them with the loop's exit test and sinks them to the loop latch, where the next fold waits.
+            // (Requested only at the END of this transform -- 64 fewer live registers during it -- measured 3 % slower.)
+#ifndef K8_NO_SAMPLE
+            const int nbu = __builtin_amdgcn_readfirstlane(nb);
+            load_x(pa, nbu, 0);
+            load_x(pb, nbu, kN8 / 2);
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
+        twist(x, h);
+        dft16(x);
+        mul_tw1(x, tw1);
+        if (swap_tw1) load_tw1_half(h ^ 1);
+        if (lead) __syncthreads();
+        xchg_a2_write(img0, x, t);
+        __syncthreads();
+        xchg_b2_read(img0, x, t);
+        dft16(x);
+        const float4 r0 = tw2row[0], r1 = tw2row[1];
+        loc_write16(loc_m0, x);
+        wave_lds_order();
+        loc_read16(smem + loc_rd, x);
+        dft16_tw_row(x, tw2row, r0, r1);
+        ++seq;
+    };
+
+    load_x(pa, 0, 0);
+    load_x(pb, 0, kN8 / 2);
+    load_tw1_half(0);
+    int q0 = 0;                            // first pair of the generic loop below
+    int ni = 0, nj = 1;                    // default list: the pair the generic loop is at
+#ifdef K8_NO_FWD
+    if (n_win < 0)
+#endif
+    if (!pairs && B >= 2) {
+        // ---- default pair list: the first anchor's run INTERLEAVED with the forward transforms, k_win's schedule.  With all
+        // forward transforms of a window in one block every CU of the chip streams spectra out (and samples in) at the same
+        // time and a forward half transform takes 6.9 us against 4.2-4.5 on a half-empty chip (a pair half transform: 3.3
+        // either way); spread over the first run's pairs the chip-wide rate halves.  X_0 is never stored: its half 0 goes
+        // straight into the anchor registers, its half 1 into the LDS anchor; every further X_j is transformed, stored and
+        // used at once, from registers, for the pair (0, j).
+        float2 x[16];
+        cvt_x(pa);
+        cvt_x(pb);
+        fwd_half(std::integral_constant<int, 0>{}, x, true, true, 0);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) sa.set(q, x[q].x, x[q].y);
+        fwd_half(std::integral_constant<int, 1>{}, x, true, true, 1);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) anc[j * kThreads + t] = make_float4(x[2 * j].x, x[2 * j].y, x[2 * j + 1].x, x[2 * j + 1].y);
+        for (int j = 1; j < B; ++j) {
+            float2 v[16];
+            cvt_x(pa);
+            cvt_x(pb);
+            // ---- half 0: X_j,0, stored for the later anchors, and e_0 of (0, j)
+            fwd_half(std::integral_constant<int, 0>{}, x, j == 1, false, 0);
+#ifndef K8_NO_STORE
+            store_spec(x, 2 * j);
+#endif
+            pair_h1(std::integral_constant<int, 0>{}, x, [&](auto) __attribute__((always_inline)) {});
+            barrier_hook(false);
+            xchg_a2_read(img0, v, t);
+            __syncthreads();
+            pair_h2(std::integral_constant<int, 0>{}, v, j - 1, std::false_type{});
+            // ---- half 1
+            fwd_half(std::integral_constant<int, 1>{}, x, false, false, j + 1 < B ? j + 1 : j);
+#ifndef K8_NO_STORE
+            store_spec(x, 2 * j + 1);
+#endif
+            pair_h1(std::integral_constant<int, 1>{}, x, [&](auto) __attribute__((always_inline)) {});
+            barrier_hook(false);
+            xchg_a2_read(img0, v, t);
+            __syncthreads();
+            pair_h2(std::integral_constant<int, 1>{}, v, j - 1, std::false_type{});
+        }
+        q0 = B - 1;
+        nj = B - 1;                        // (the generic loop's pair counters stand at (0, B - 1))
+    } else {
+        // ---- a custom pair list: all forward transforms first, every spectrum stored
+        for (int b = 0; b < B; ++b) {
+            float2 x[16];
+            cvt_x(pa);
+            cvt_x(pb);
+            fwd_half(std::integral_constant<int, 0>{}, x, true, true, 0);
+#ifndef K8_NO_STORE
+            store_spec(x, 2 * b);
+#endif
+            fwd_half(std::integral_constant<int, 1>{}, x, true, true, b + 1 < B ? b + 1 : b);
+#ifndef K8_NO_STORE
+            store_spec(x, 2 * b + 1);
+#endif
+        }
+        __syncthreads();
+    }
+
+    if (q0 < n_pairs) {
         // (i, j) of pair q: the default list (pairs == nullptr) is the nested loop i < j -- two counters, no memory access;
         // a custom list is read from its copy in LDS (a scalar load here would share lgkmcnt with the exchanges)
-        int ni = 0, nj = 1;
         auto next_pair = [&](int q) -> Pair2 {            // pair q, called with q = 1, 2, 3, ... in order
             if (!pairs) {
                 if (++nj >= B) { ++ni; nj = ni + 1; }
@@ -498,17 +577,19 @@ __global__ __launch_bounds__(kThreads, 2) void k_win8kl(const void* __restrict__
             const int2 v = reinterpret_cast<const int2*>(plist)[q];
             return Pair2{__builtin_amdgcn_readfirstlane(v.x), __builtin_amdgcn_readfirstlane(v.y)};
         };
-        Pair2 cur = pairs ? Pair2{__builtin_amdgcn_readfirstlane(plist[0].i), __builtin_amdgcn_readfirstlane(plist[0].j)} : Pair2{0, 1};
+        Pair2 cur = pairs ? Pair2{__builtin_amdgcn_readfirstlane(plist[0].i), __builtin_amdgcn_readfirstlane(plist[0].j)}
+                          : (q0 ? next_pair(q0) : Pair2{0, 1});
         all_parts(sa, 2 * cur.i);
         all_parts(ev, 2 * cur.i + 1);
         all_parts(sb, 2 * cur.j);
-        load_tw1_half(0);                      // (phase 1 left half 1's table in the registers)
-        park_anchor();
+        park_anchor();                         // (phase 1 left half 0's TW1 table in the registers)
         pair_h1(std::integral_constant<int, 0>{}, sb, [&](auto part) __attribute__((always_inline)) {
+#ifndef K8_NO_SPEC
             load_spec_part(sb, 2 * cur.j + 1, part);           // the same pair's half 1
+#endif
         });
         bool pend_anchor = false;
-        for (int q = 0; q < n_pairs; ++q) {
+        for (int q = q0; q < n_pairs; ++q) {
             const bool has_next = q + 1 < n_pairs;
             const Pair2 nxt = has_next ? next_pair(q + 1) : cur;
             const bool new_anchor = has_next && nxt.i != cur.i;
@@ -516,28 +597,36 @@ __global__ __launch_bounds__(kThreads, 2) void k_win8kl(const void* __restrict__
             // ---- half 0
             barrier_hook(false);
             xchg_a2_read(img0, v, t);
+#ifndef K8_NO_B2
             __syncthreads();                    // every wave holds its inputs: the image is free for the next transform
+#endif
             if (pend_anchor) park_anchor();     // (requested one transform ago into ev, which half 0 overwrites just below)
             pend_anchor = false;
-            pair_h2(std::integral_constant<int, 0>{}, v, q);
+            pair_h2(std::integral_constant<int, 0>{}, v, q, std::false_type{});
             pair_h1(std::integral_constant<int, 1>{}, sb, [&](auto part) __attribute__((always_inline)) {
+#ifndef K8_NO_SPEC
                 if constexpr (decltype(part)::value == 0) {
                     if (new_anchor) all_parts(sa, 2 * nxt.i);                  // sa is idle during this half (the anchor comes from LDS)
                 }
                 load_spec_part(sb, 2 * nxt.j, part);           // next pair's half 0 (behind the last pair: an index that exists)
+#endif
             });
             ++seq;
             // ---- half 1
             barrier_hook(false);
             xchg_a2_read(img0, v, t);
+#ifndef K8_NO_B2
             __syncthreads();
-            pair_h2(std::integral_constant<int, 1>{}, v, q);
+#endif
+            pair_h2(std::integral_constant<int, 1>{}, v, q, std::false_type{});
             if (has_next) {
                 pair_h1(std::integral_constant<int, 0>{}, sb, [&](auto part) __attribute__((always_inline)) {
+#ifndef K8_NO_SPEC
                     if constexpr (decltype(part)::value == 0) {
                         if (new_anchor) all_parts(ev, 2 * nxt.i + 1);          // e_0 is dead until the next half 0
                     }
                     load_spec_part(sb, 2 * nxt.j + 1, part);
+#endif
                 });
                 pend_anchor = new_anchor;
             }
