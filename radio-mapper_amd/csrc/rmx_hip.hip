@@ -1419,7 +1419,9 @@ static int generic_batch(rmx_ctx* c, const void* d_iq, int n_windows, int n_pair
     const long ws_blocks = ((long)n_windows + (c->g_ws_upw > 0 ? c->g_ws_upw : 1) - 1) / (c->g_ws_upw > 0 ? c->g_ws_upw : 1);
     // (L = 32768, g_win_eo15: it wins from about 0.7 workgroups per CU on for 2 ... 16 buoys -- 0.67-0.79 x the four-step's time
     // at 256 windows, 0.85-0.94 x at 192, 0.9-1.25 x at 128: profiles/r03_weo_sweep.log)
-    const bool use_wscr = c->g_wscr && (c->g_wscr_always || ws_blocks >= (c->g_logL == 14 ? 7L : 11L) * c->n_cus / 16);
+    // (L = 16384 through k_win8kl: 242 us for anything up to one window per CU at 8 buoys, 50 us at 3, against 194 / 50 us at
+    // 64 windows and 290 / 64 us at 96 through the per-transform kernels -- tools/exp_k8_small.py: from 5/16 of a workgroup per CU)
+    const bool use_wscr = c->g_wscr && (c->g_wscr_always || ws_blocks >= (c->g_logL == 14 ? (c->g_k8 ? 5L : 7L) : 11L) * c->n_cus / 16);
     const bool whole_window = c->g_wfused || use_wscr;   // those kernels keep no per-window state in HBM
     int rc = generic_ensure(c, n_pairs, !whole_window, !whole_window);
     if (rc) return rc;

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """GPU box: where k_win8kl's time goes -- the same B buoys x W windows with pair lists of 1, B-1, P/2, P pairs (custom lists
-in the default order): time = forward part + pairs x per-pair cost.   usage: exp_k8_split.py [B W]"""
+in the default order): time = forward part + pairs x per-pair cost.   usage: exp_k8_split.py [B W [N]]   (N = 16384: g_win_eo15)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -11,6 +11,8 @@ from radio_mapper_amd import xcorr
 B, N, W = 8, 8192, 512
 if len(sys.argv) > 2:
     B, W = int(sys.argv[1]), int(sys.argv[2])
+if len(sys.argv) > 3:
+    N = int(sys.argv[3])
 xcorr.set_default_option("wscr", 2)
 dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev); g.manual_seed(3)
