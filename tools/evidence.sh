@@ -10,3 +10,20 @@ for c in cfg3 cfg2 cfg4 cfg5 cfg1; do python bench.py --config $c > gpurun_out/$
 tools/profile.sh $tag > gpurun_out/profile_$tag.log 2>&1; python tools/summarize_prof.py gpurun_out/prof_$tag $tag | tail -2
 for c in cfg2 cfg4 cfg5; do tools/profile.sh ${tag}_$c $c > gpurun_out/profile_${tag}_$c.log 2>&1; python tools/summarize_prof.py gpurun_out/prof_${tag}_$c ${tag}_$c $c | tail -2; done
 cp profiles/${tag}* profiles/traffic_* gpurun_out/ 2>/dev/null
+# round 5: the N = 8192 kernel (k_win8kl) -- sweep against g_win_scr14, forward / pair split, rocprofv3 kernel stats of a full batch;
+# the 32-column-tile experiment of the four-step column kernels
+python tools/exp_k8_sweep.py 2>&1 | grep -v amdgpu.ids > profiles/${tag}_n8192_sweep.txt; tail -3 profiles/${tag}_n8192_sweep.txt
+{ python tools/exp_k8_split.py 8 512; python tools/exp_k8_split.py 8 128; python tools/exp_k8_split.py 3 1024; python tools/exp_k8_split.py 8 256 16384; } 2>&1 | grep -v amdgpu.ids > profiles/${tag}_n8192_split.txt
+python tools/exp_k8_small.py 2>&1 | grep -v amdgpu.ids > profiles/${tag}_n8192_small.txt
+python tools/exp_cols32.py 2>&1 | grep -v amdgpu.ids > profiles/${tag}_cols32.txt
+( export TMPDIR=/tmp; R=$PWD; cd /tmp && RMX_WSCR=2 rocprofv3 --kernel-trace --stats -T -f csv -d $R/gpurun_out/prof_${tag}_n8192 -o stats -- python3 $R/tools/bench_cfg.py 8 8192 512 30 > $R/gpurun_out/prof_${tag}_n8192.log 2>&1 )
+python - <<PY
+import csv, glob
+st = glob.glob("gpurun_out/prof_${tag}_n8192/**/*kernel_stats.csv", recursive=True)
+if st:
+    rows = list(csv.reader(open(st[0])))
+    keep = [rows[0]] + [r for r in rows[1:] if "k_win8" in r[0] or "g_win" in r[0]]
+    csv.writer(open("profiles/${tag}_n8192_kernel_stats.csv", "w", newline="")).writerows(keep)
+    print(keep[1][:4] if len(keep) > 1 else "no k_win8kl row")
+PY
+cp profiles/${tag}* profiles/traffic_* profiles/pmc_latest.json gpurun_out/ 2>/dev/null
