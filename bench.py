@@ -746,7 +746,6 @@ def main():
         projection = strong_scaling_projection(torch, sh, sync_all)
         region_order.append("strong_scaling_projection (cfg3 on W/G windows, G = 1, 2, 4, 8)")
 
-    eng.set_option("timing", 1)   # HIP events around every launch, on the launch stream
     for _ in range(warm):
         step()
     # (a) HEADLINE: the driver's contract and nothing else -- W warm-up steps of this shape, then exactly K timed steps
@@ -767,19 +766,21 @@ def main():
     sus_elapsed, sus_region_ms = timed_steps(torch, sh, steps, sync_all)
     ms_per_step_sustained = max_over_ranks(sus_elapsed) * 1e3 / steps
     region_order += [f"prewarm ({prewarm} steps)", f"timed sustained region ({steps} steps)"]
-    # kernel durations from the HIP events bracketing every launch on the launch stream: the last
-    # step of the timed region, then the same step repeated with a read-back after each
+    # kernel durations from HIP events bracketing every launch on the launch stream: a few more steps with option
+    # "timing" on, a read-back after each (OUTSIDE the timed regions: two event records per launch are a tenth of a
+    # cfg1 step, which is five launches of 6-22 us)
     fwd_ms = pair_ms = 0.0
     fwd_n = pair_n = 0
     n_meas = max(min(steps, 10 if not caf else 1), 1)
     by_kernel = None
+    eng.set_option("timing", 1)
     for k in range(n_meas):
-        if k > 0:
-            step()
+        step()
         tm = eng.last_timing()
         fwd_ms += tm["fwd_ms"]; fwd_n += tm["fwd_launches"]
         pair_ms += tm["pair_ms"]; pair_n += tm["pair_launches"]
         by_kernel = eng.last_timing_by_kernel()
+    eng.set_option("timing", 0)
     seen = ranks_seen()
 
     # PCIe-inclusive rate of the same step through the host-pointer entry of the C ABI (reported, never `value`):

@@ -832,6 +832,61 @@ def test_whole_window_scratch_kernel_by_length(xc, N, B, opts):
     assert np.array_equal(ui, li) and np.all(np.abs(uf - lf) <= TOL) and np.allclose(up, pk, rtol=1e-5)
 
 
+@pytest.mark.parametrize("kwin8k", [1, 0])
+def test_edge_cases_n8192_whole_window_kernels(xc, opts, kwin8k):
+    """The edge windows of test_edge_cases_n4096 at the reference's streaming capture length (iq_stream_client.py:459) through
+    the whole-window kernels (option wscr = 2; kwin8k = 1: k_win8kl, 0: g_win_scr14): zeros (every lag ties -> the lowest
+    index, the kernels' exact-tie path), impulses, peaks on both edges, two peaks of equal height, constant inputs; raw
+    uint8 identical.  Random data never reaches the tie path of the wave-level search."""
+    N = 8192
+    e = np.zeros((6, 2, N), np.complex64)
+    e[1, 0, 5] = 1.0; e[1, 1, 25] = 2.0 - 1.0j
+    e[2, 0, 0] = 3.0; e[2, 1, N - 1] = 1.0j
+    e[3, 0, N - 1] = 1.0; e[3, 1, 0] = -2.0
+    e[4, 0, 100] = 1.0; e[4, 1, 93] = 1.0; e[4, 1, 109] = 1.0
+    e[5, 0, :] = 4.5 - 2.5j; e[5, 1, :] = -1.5 + 0.5j
+    ri, rf, rp = orc.xcorr_batch_literal(e)
+    opts("wscr", 2)
+    opts("kwin8k", kwin8k)
+    with xc.XcorrEngine(2, N, 6) as eng:
+        li, lf, pk = eng.correlate(e)
+        both = eng.correlate(e, pairs=np.array([[0, 1], [1, 0], [0, 1]], np.int32))
+    assert li[0, 0] == -(N - 1) and lf[0, 0] == 0.0 and pk[0, 0] == 0.0      # all ties -> lowest index
+    assert li[1, 0] == ri[1, 0] == 20
+    assert li[2, 0] == ri[2, 0] == N - 1 and lf[2, 0] == 0.0
+    assert li[3, 0] == ri[3, 0] == -(N - 1) and lf[3, 0] == 0.0
+    margin4, first4, second4 = orc.peak_top2(e[4, 0], e[4, 1])
+    assert {first4, second4} == {-7, 9} and margin4 <= TOL and li[4, 0] in (first4, second4)
+    cond = float(rp[5, 0]) / abs(2.0 * float(rp[5, 0]) / N)
+    assert li[5, 0] == ri[5, 0] == 0 and abs(lf[5, 0] - rf[5, 0]) <= max(TOL, 4 * 6e-8 * cond)
+    assert np.allclose(pk[1:], rp[1:], rtol=1e-5)
+    # a custom list (forward-first order in k_win8kl): (0,1), its mirror image, (0,1) again
+    assert np.array_equal(both[0][:, 0], li[:, 0]) and np.array_equal(both[0][:, 2], li[:, 0])
+    assert np.array_equal(both[0][[1, 2, 3, 5], 1], -li[[1, 2, 3, 5], 0]) and both[0][0, 1] == -(N - 1)
+
+
+def test_n8192_pair_lists_beyond_the_lds_copy(xc, opts):
+    """k_win8kl keeps a custom pair list in LDS (640 entries); a longer one takes g_win_scr14.  700 pairs (repeats, both orders)
+    on 6 buoys x 260 windows against the oracle's answer for the 30 distinct ordered pairs."""
+    N, B, W = 8192, 6, 260
+    iq = rm.synth.make_windows(W, B, N, 2.4e6, seed=61)[0]
+    rng = np.random.default_rng(9)
+    a = rng.integers(0, B, size=700)
+    b = (a + rng.integers(1, B, size=700)) % B
+    pairs = np.stack([a, b], axis=1).astype(np.int32)
+    distinct = np.array([(i, j) for i in range(B) for j in range(B) if i != j], np.int32)
+    ri, rf, rp = orc.xcorr_batch_fast(iq[:8], distinct, workers=8)
+    col = {(int(i), int(j)): k for k, (i, j) in enumerate(distinct)}
+    idx = np.array([col[(int(i), int(j))] for i, j in pairs])
+    opts("wscr", 2)
+    with xc.XcorrEngine(B, N, W) as eng:
+        li, lf, pk = eng.correlate(iq, pairs)
+        si, sf, sp = eng.correlate(iq, pairs[:600])              # 600 <= 640: k_win8kl
+    _assert_parity(li[:8], lf[:8], pk[:8], ri[:, idx], rf[:, idx], rp[:, idx])
+    _assert_parity(si[:8], sf[:8], sp[:8], ri[:, idx[:600]], rf[:, idx[:600]], rp[:, idx[:600]])
+    assert np.array_equal(li[:, :600], si) and np.all(np.abs(lf[:, :600] - sf) <= TOL)
+
+
 @pytest.mark.parametrize("case", range(12))
 def test_seeded_random_shapes_and_pair_lists(xc, case):
     """Seeded sweep over (buoys, window length, windows, pair list): every kernel family gets shapes nobody
