@@ -8,7 +8,7 @@ python -m pytest tests -m gpu -x -q > gpurun_out/${tag}_final_pytest.log 2>&1; e
 # (the default line = cfg3 with the other four shapes inside it; the per-shape lines below are each shape's own full line)
 for c in cfg3 cfg2 cfg4 cfg5 cfg1; do python bench.py --config $c > gpurun_out/${tag}_bench_$c.log 2>&1; echo "$c rc=$?"; tail -1 gpurun_out/${tag}_bench_$c.log | cut -c1-200; tail -1 gpurun_out/${tag}_bench_$c.log > profiles/${tag}_bench_$c.json; done
 tools/profile.sh $tag > gpurun_out/profile_$tag.log 2>&1; python tools/summarize_prof.py gpurun_out/prof_$tag $tag | tail -2
-for c in cfg2 cfg4 cfg5; do tools/profile.sh ${tag}_$c $c > gpurun_out/profile_${tag}_$c.log 2>&1; python tools/summarize_prof.py gpurun_out/prof_${tag}_$c ${tag}_$c $c | tail -2; done
+for c in cfg2 cfg4 cfg5 cfg1; do tools/profile.sh ${tag}_$c $c > gpurun_out/profile_${tag}_$c.log 2>&1; python tools/summarize_prof.py gpurun_out/prof_${tag}_$c ${tag}_$c $c | tail -2; done
 cp profiles/${tag}* profiles/traffic_* gpurun_out/ 2>/dev/null
 # round 5: the N = 8192 kernel (k_win8kl) -- sweep against g_win_scr14, forward / pair split, rocprofv3 kernel stats of a full batch;
 # the 32-column-tile experiment of the four-step column kernels
@@ -25,5 +25,33 @@ if st:
     keep = [rows[0]] + [r for r in rows[1:] if "k_win8" in r[0] or "g_win" in r[0]]
     csv.writer(open("profiles/${tag}_n8192_kernel_stats.csv", "w", newline="")).writerows(keep)
     print(keep[1][:4] if len(keep) > 1 else "no k_win8kl row")
+PY
+cp profiles/${tag}* profiles/traffic_* profiles/pmc_latest.json gpurun_out/ 2>/dev/null
+# cfg1 (one window per call, five launches): durations and gaps between consecutive kernels of a step from the kernel trace
+python - <<PY
+import csv, glob, statistics as st
+tr = glob.glob("gpurun_out/prof_${tag}_cfg1/stats/**/*kernel_trace.csv", recursive=True)
+if tr:
+    rows = sorted((r for r in csv.DictReader(open(tr[0])) if r["Kernel_Name"].startswith(("void rmx::gen::g_", "rmx::gen::g_"))), key=lambda r: int(r["Start_Timestamp"]))
+    names = ["g_cols_fwd", "g_rows<", "g_rows<", "g_cols_inv", "g_final"]
+    steps = []
+    i = 0
+    while i + 5 <= len(rows):
+        blk = rows[i:i + 5]
+        if all(n in b["Kernel_Name"] for n, b in zip(names, blk)):
+            steps.append(blk); i += 5
+        else:
+            i += 1
+    out = ["# cfg1: one rmx_xcorr_batch call = five launches; medians over %d steps of bench.py --config cfg1 --profile under rocprofv3 --kernel-trace" % len(steps)]
+    if steps:
+        for k in range(5):
+            d = st.median(int(s[k]["End_Timestamp"]) - int(s[k]["Start_Timestamp"]) for s in steps)
+            g = st.median(int(s[k + 1]["Start_Timestamp"]) - int(s[k]["End_Timestamp"]) for s in steps) if k < 4 else float("nan")
+            out.append("%-12s duration %7.2f us   gap to the next kernel %6.2f us" % (names[k].rstrip("<"), d / 1e3, g / 1e3))
+        span = st.median(int(s[4]["End_Timestamp"]) - int(s[0]["Start_Timestamp"]) for s in steps)
+        nxt = st.median(int(b[0]["Start_Timestamp"]) - int(a[4]["End_Timestamp"]) for a, b in zip(steps, steps[1:])) if len(steps) > 1 else float("nan")
+        out.append("first start -> last end %.2f us; gap to the next call's first kernel %.2f us" % (span / 1e3, nxt / 1e3))
+    open("profiles/${tag}_cfg1_gaps.txt", "w").write("\n".join(out) + "\n")
+    print("\n".join(out))
 PY
 cp profiles/${tag}* profiles/traffic_* profiles/pmc_latest.json gpurun_out/ 2>/dev/null
