@@ -1,8 +1,9 @@
 // kwin8k.hpp -- k_win8kl: the reference's streaming capture length N = 8192 (iq_stream_client.py:459) on the machinery of
 // the fused N = 4096 kernel (kwin.hpp / fft_r16.hpp).  Round 4 built the first two versions (tools/experiments/kwin8k.hpp:
 // k_win8k without a resident anchor, k_win8ka with both anchor halves in registers: neither beat g_win_scr14); round 5's
-// third version, with ONE bin-parity half of the anchor resident in LDS, does (8 buoys x 512 windows 0.60 against 0.73 ms,
-// 16 x 256 1.10 against 1.42, 3 x 1024 0.27 against 0.285) and is the product kernel for batches that fill the chip.
+// third version -- ONE bin-parity half of the anchor resident in LDS, the first anchor's pairs interleaved with the forward
+// transforms -- does (8 buoys x 512 windows 0.52 against 0.73 ms, 16 x 256 1.00 against 1.42, 3 x 1024 0.21 against 0.285) and is
+// the product kernel from 5/16 of a workgroup per CU on (rmx_hip.hip: generic_batch; option kwin8k = 0: g_win_scr14).
 //
 // A window zero-padded from N = 8192 to L = 16384 splits by bin parity h into two 8192-point transforms,
 //     X[2 kappa + h] = FFT_8192( x[n] W_L^(h n) )[kappa],
@@ -17,9 +18,11 @@
 //            is computed, then r[m] = e_0 + T, r[m + 8192] = e_0 - T with T = W_L^(-m) e_1 (the twist is half 1's own
 //            sub-transform twist; lanes p = 1 hold m = n + 4096 and take the extra factor +i), |.|^2 of both, and the
 //            peak search over the thread's 32 values.
-// Per window: 2 B forward transforms, all stored (B x 128 KiB of the workgroup's scratch), then 2 P pair transforms; the
-// TW1 table of the other half is re-requested behind its last use, the TW2 row comes from LDS (the 30 registers go to
-// e_0).  Any pair list (an anchor run = consecutive pairs with the same first buoy).
+// Per window: 2 B forward and 2 P pair transforms; the TW1 table of the other half is re-requested behind its last use, the
+// TW2 row comes from LDS (the 30 registers go to e_0).  Default pair list: k_win's schedule -- X_0 straight into the anchor
+// (never stored), every further X_j transformed, stored and used at once for (0, j), then the anchors 1 ... B-2 with X_j
+// streaming.  Any other pair list: all forward transforms first (an anchor run = consecutive pairs with the same first buoy).
+// Scratch per persistent workgroup: [b][half] x 64 KiB in thread-register order.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -139,8 +142,8 @@ __device__ __forceinline__ int first_slot_eq(const float (&m)[16], float t) {
 
 // ---- k_win8kl: ONE bin-parity half of the anchor spectrum resident in LDS -----------------------------------------------
 // The limit of a kernel without a resident anchor (k_win8k, tools/experiments/) is the scratch traffic of an anchor that
-// alternates between its two halves (9 MiB per window at 8 buoys); two register-resident halves (k_win8ka) spill.  Here X_i's half 0 stays in the 32 anchor registers and its half 1 in
-// 64 KiB of LDS (thread-private columns: every thread reads back the float4s it stored, conflict free) for the whole run of
+// alternates between its two halves (9 MiB per window at 8 buoys); two register-resident halves (k_win8ka) spill.  Here
+// X_i's half 0 stays in the 32 anchor registers and its half 1 in 64 KiB of LDS (thread-private columns: every thread reads back the float4s it stored, conflict free) for the whole run of
 // pairs that share the anchor; per transform only the streamed X_j,h travels (4.4 MiB of scratch reads per window at 8 buoys
 // instead of 8).  The 64 KiB come out of the second exchange image, so a transform pays a second workgroup barrier (behind
 // its role-A reads) and the half-order staggering is gone.
