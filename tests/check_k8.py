@@ -1,6 +1,7 @@
-"""GPU box: k_win8k (N = 8192 on the fused kernel's network) -- determinism, complex64 against raw uint8, the oracle, the
-product kernel g_win_scr14 (option kwin8k = 0).  Needs a -DRMX_EXPERIMENTS library:
-    RMX_LIBRARY=/path/librmx_exp.so python tests/check_k8.py"""
+"""GPU box: the N = 8192 kernels on the fused kernel's network -- determinism, complex64 against raw uint8, the oracle, and
+g_win_scr14 (option kwin8k = 0).  Default: the product's k_win8kl (kwin8k = 1).  `python tests/check_k8.py 2` checks the shelved
+k_win8k instead and needs a -DRMX_EXPERIMENTS library (RMX_LIBRARY=/path/librmx_exp.so).  (The suite's own coverage of
+k_win8kl: tests/test_gpu_parity.py, test_whole_window_scratch_kernel_by_length and the two N = 8192 tests behind it.)"""
 import sys, time
 sys.path.insert(0, '/root/repo')
 import numpy as np
@@ -8,10 +9,11 @@ import radio_mapper_amd as rm
 from radio_mapper_amd import xcorr
 from oracle import xcorr_ref as orc
 N = 8192
+KIND = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 for B, W in ((3, 300), (8, 300), (5, 2), (2, 600)):
     iq, d, raw = rm.synth.make_windows(W, B, N, 2.4e6, seed=800 + B, return_u8=True)
     xcorr.set_default_option("wscr", 2)
-    xcorr.set_default_option("kwin8k", 1)
+    xcorr.set_default_option("kwin8k", KIND)
     with xcorr.XcorrEngine(B, N, W) as eng:
         a = eng.correlate(iq)
         b = eng.correlate(iq)

@@ -32,13 +32,13 @@ python - <<PY
 import csv, glob, statistics as st
 tr = glob.glob("gpurun_out/prof_${tag}_cfg1/stats/**/*kernel_trace.csv", recursive=True)
 if tr:
-    rows = sorted((r for r in csv.DictReader(open(tr[0])) if r["Kernel_Name"].startswith(("void rmx::gen::g_", "rmx::gen::g_"))), key=lambda r: int(r["Start_Timestamp"]))
-    names = ["g_cols_fwd", "g_rows<", "g_rows<", "g_cols_inv", "g_final"]
+    rows = sorted((r for r in csv.DictReader(open(tr[0])) if r["Kernel_Name"].startswith(("g_cols", "g_rows", "g_final"))), key=lambda r: int(r["Start_Timestamp"]))
+    names = ["g_cols_fwd", "g_rows", "g_rows", "g_cols_inv", "g_final"]
     steps = []
     i = 0
     while i + 5 <= len(rows):
         blk = rows[i:i + 5]
-        if all(n in b["Kernel_Name"] for n, b in zip(names, blk)):
+        if all(b["Kernel_Name"].startswith(n) for n, b in zip(names, blk)):
             steps.append(blk); i += 5
         else:
             i += 1
@@ -49,7 +49,8 @@ if tr:
             g = st.median(int(s[k + 1]["Start_Timestamp"]) - int(s[k]["End_Timestamp"]) for s in steps) if k < 4 else float("nan")
             out.append("%-12s duration %7.2f us   gap to the next kernel %6.2f us" % (names[k].rstrip("<"), d / 1e3, g / 1e3))
         span = st.median(int(s[4]["End_Timestamp"]) - int(s[0]["Start_Timestamp"]) for s in steps)
-        nxt = st.median(int(b[0]["Start_Timestamp"]) - int(a[4]["End_Timestamp"]) for a, b in zip(steps, steps[1:])) if len(steps) > 1 else float("nan")
+        gaps = [g for g in (int(b[0]["Start_Timestamp"]) - int(a[4]["End_Timestamp"]) for a, b in zip(steps, steps[1:])) if g < 20000]   # back-to-back calls only
+        nxt = st.median(gaps) if gaps else float("nan")
         out.append("first start -> last end %.2f us; gap to the next call's first kernel %.2f us" % (span / 1e3, nxt / 1e3))
     open("profiles/${tag}_cfg1_gaps.txt", "w").write("\n".join(out) + "\n")
     print("\n".join(out))
