@@ -1411,6 +1411,24 @@ static int generic_pairs(rmx_ctx* c, int w0, int wc, int n_pairs, int* d_lag, fl
     return RMX_OK;
 }
 
+// windows [w0, w0 + n) of a batch through the four-step kernels (the partial last round behind a whole-window kernel's full
+// rounds, same stream): buffers on first need, chunks as in generic_batch's own loop
+static int four_step_windows(rmx_ctx* c, const void* d_iq, int w_first, int n, int n_pairs, int* d_lag, float* d_frac,
+                             float* d_peak, bool u8) {
+    int rc = generic_ensure(c, n_pairs, true, true);
+    if (rc) return rc;
+    for (int w0 = w_first; w0 < w_first + n; w0 += c->g_chunk) {
+        const int wc = w_first + n - w0 < c->g_chunk ? w_first + n - w0 : c->g_chunk;
+        const long fused_blocks = c->g_fused ? (long)wc * (1L << c->g_logL1) / (gen::kGThreads / ((1 << c->g_logL2) >> 4)) : 0;
+        const bool fused = c->g_fused && (fused_blocks >= 2L * c->n_cus || c->g_fused_always);
+        rc = generic_forward(c, d_iq, w0, wc, u8, nullptr, fused);
+        if (rc) return rc;
+        rc = generic_pairs(c, w0, wc, n_pairs, d_lag, d_frac, d_peak, false, fused);
+        if (rc) return rc;
+    }
+    return RMX_OK;
+}
+
 static int generic_batch(rmx_ctx* c, const void* d_iq, int n_windows, int n_pairs, int* d_lag, float* d_frac,
                          float* d_peak, bool u8) {
     // g_win_scr runs a window's B + P transforms one after the other in one workgroup: batches that leave most of the chip
@@ -1441,6 +1459,20 @@ static int generic_batch(rmx_ctx* c, const void* d_iq, int n_windows, int n_pair
             const float out_scale = std::ldexp(1.0f, 3 * kTw1ScaleLog2 - 14);
             const k8::Pair2* prs = def_list ? nullptr : reinterpret_cast<const k8::Pair2*>(c->g_pairs);
             const int stag = (int)c->knobs.get_or("stag", 1);
+            // The batch's last, partial round (W mod CUs windows behind at least one full round) costs this kernel a whole
+            // round whatever its size -- 3.5 us per half transform: 245 us at 8 buoys, 50 at 3 --, the four-step kernels about
+            // 30 us + 0.07 us per window and spectrum-or-pair (tools/exp_k8_small.py: 8 buoys 104 us for 32 windows, 140 for 48;
+            // 3 buoys 43 / 47) plus four more launches.  The cheaper one runs, on the same stream behind the full rounds:
+            // 8 buoys x 300 windows 507 -> 444 us, x 560 762 -> 710; 3 buoys never split.  Not with wscr = 2 (tests force the kernel).
+            int n_tail = 0;
+            if (!c->g_wscr_always && n_windows > c->g_ws_grid) {
+                const int r = n_windows % c->g_ws_grid;
+                const double round_us = 3.5 * (2.0 * c->n_buoys + 2.0 * n_pairs);
+                const double four_us = 40.0 + 0.07 * r * (double)(c->n_buoys + n_pairs);
+                if (r > 0 && (long)r * 16 < 5L * c->n_cus && four_us < 0.7 * round_us) n_tail = r;   // (5 buoys x 300: 234 split, 228 whole)
+            }
+            const int n_head = n_windows - n_tail;
+            n_windows = n_head;                 // (the launches below take the full rounds)
             RMX_TM_BEGIN(c);
 #ifdef RMX_EXPERIMENTS
             if (c->g_k8_kind == 2) {
@@ -1464,14 +1496,27 @@ static int generic_batch(rmx_ctx* c, const void* d_iq, int n_windows, int n_pair
                                    d_frac, d_peak, n_windows, stag);
             RMX_HIP(c, hipGetLastError());
             RMX_TM_END(c, kTkWindow);
+            if (n_tail) return four_step_windows(c, d_iq, n_head, n_tail, n_pairs, d_lag, d_frac, d_peak, u8);
             return RMX_OK;
         }
         if (logL == 15) {                          // g_win_eo15: one more table
+            // (the partial last round as above: a round costs this kernel 12.6 us per half transform -- 907 us at 8 buoys --, the
+            // four-step kernels about 0.14 us per window and spectrum-or-pair at this length)
+            int n_tail = 0;
+            if (!c->g_wscr_always && n_windows > c->g_ws_grid && c->g_ws_upw == 1) {
+                const int r = n_windows % c->g_ws_grid;
+                const double round_us = 12.6 * (2.0 * c->n_buoys + 2.0 * n_pairs);
+                const double four_us = 60.0 + 0.14 * r * (double)(c->n_buoys + n_pairs);
+                if (r > 0 && (long)r * 16 < 11L * c->n_cus && four_us < 0.85 * round_us) n_tail = r;
+            }
+            const int n_head = n_windows - n_tail;
+            a_nw = n_head;
             const float2* a_twl = c->g_tw_l;
             void* args[] = {&a_iq, &a_scr, &a_tw, &a_twl, &a_nb, &a_nw, &a_first, &a_fs, &a_os, &a_pairs, &a_np, &d_lag, &d_frac, &d_peak};
             RMX_TM_BEGIN(c);
             RMX_HIP(c, hipLaunchKernel(c->g_ws_fn[u8 ? 1 : 0], dim3((unsigned)grid), dim3(c->g_ws_thr), args, c->g_ws_lds, c->stream));
             RMX_TM_END(c, kTkWindow);
+            if (n_tail) return four_step_windows(c, d_iq, n_head, n_tail, n_pairs, d_lag, d_frac, d_peak, u8);
             return RMX_OK;
         }
         void* args[] = {&a_iq, &a_scr, &a_tw, &a_nb, &a_nw, &a_first, &a_fs, &a_os, &a_pairs, &a_np, &d_lag, &d_frac, &d_peak};

@@ -865,6 +865,57 @@ def test_edge_cases_n8192_whole_window_kernels(xc, opts, kwin8k):
     assert np.array_equal(both[0][[1, 2, 3, 5], 1], -li[[1, 2, 3, 5], 0]) and both[0][0, 1] == -(N - 1)
 
 
+@pytest.mark.parametrize("B,pairs", [(6, None), (8, None), (6, "custom")])
+def test_n8192_partial_last_round_through_the_four_step_kernels(xc, opts, B, pairs):
+    """N = 8192, W = CUs + 40 windows: k_win8kl takes the full round, the 40 windows of the partial round -- which would cost it a
+    whole round -- go through the four-step kernels on the same stream where the cost model of generic_batch says so (from
+    about five buoys on with the default pair list; a five-pair custom list of six buoys does not pay and stays whole).
+    Every window against the oracle; integer lags equal to the all-k_win8kl run (option wscr = 2) and to g_win_scr14's
+    (kwin8k = 0); timing shows which families ran."""
+    N = 8192
+    W = _device_cus() + 40
+    iq = rm.synth.make_windows(W, B, N, 2.4e6, seed=77 + B)[0]
+    pl = None if pairs is None else np.array([(B - 1, 0), (0, 2), (0, 1), (3, 1), (3, 4)], np.int32)
+    chk = np.r_[0:6, W - 46:W]                                   # oracle on windows of the full round and all of the tail
+    ri, rf, rp = orc.xcorr_batch_fast(iq[chk], pl, workers=8)
+    with xc.XcorrEngine(B, N, W) as eng:
+        eng.set_option("timing", 1)
+        li, lf, pk = eng.correlate(iq, pl)
+        fam = eng.last_timing_by_kernel()
+    assert fam["g_win_*"]["launches"] == 1 and ("g_cols_inv" in fam) == (pairs is None), fam
+    _assert_parity(li[chk], lf[chk], pk[chk], ri, rf, rp)
+    for k, v in (("wscr", 2), ("kwin8k", 0)):
+        xc.clear_default_options()
+        opts(k, v)
+        with xc.XcorrEngine(B, N, W) as eng:
+            eng.set_option("timing", 1)
+            ai, af, ap = eng.correlate(iq, pl)
+            fam2 = eng.last_timing_by_kernel()
+        assert np.array_equal(ai, li) and np.all(np.abs(af - lf) <= TOL) and np.allclose(ap, pk, rtol=1e-5), k
+        if k == "wscr":
+            assert set(fam2) == {"g_win_*"}                      # forced: no split
+
+
+def test_n16384_partial_last_round_through_the_four_step_kernels(xc, opts):
+    """The same for g_win_eo15 (N = 16384, buoy_node.py:364): W = CUs + 24 windows of 5 buoys -- the 24 windows of the partial
+    round through the four-step kernels; against the oracle on both parts, integer lags equal to the all-g_win_eo15 run."""
+    N, B = 16384, 5
+    W = _device_cus() + 24
+    iq = rm.synth.make_windows(W, B, N, 2.4e6, seed=515)[0]
+    chk = np.r_[0:4, W - 26:W]
+    ri, rf, rp = orc.xcorr_batch_fast(iq[chk], workers=8)
+    with xc.XcorrEngine(B, N, W) as eng:
+        eng.set_option("timing", 1)
+        li, lf, pk = eng.correlate(iq)
+        fam = eng.last_timing_by_kernel()
+    assert fam["g_win_*"]["launches"] == 1 and "g_cols_inv" in fam, fam
+    _assert_parity(li[chk], lf[chk], pk[chk], ri, rf, rp)
+    opts("wscr", 2)
+    with xc.XcorrEngine(B, N, W) as eng:
+        ai, af, ap = eng.correlate(iq)
+    assert np.array_equal(ai, li) and np.all(np.abs(af - lf) <= TOL) and np.allclose(ap, pk, rtol=1e-5)
+
+
 def test_n8192_pair_lists_beyond_the_lds_copy(xc, opts):
     """k_win8kl keeps a custom pair list in LDS (640 entries); a longer one takes g_win_scr14.  700 pairs (repeats, both orders)
     on 6 buoys x 260 windows against the oracle's answer for the 30 distinct ordered pairs."""
