@@ -56,3 +56,6 @@ if tr:
     print("\n".join(out))
 PY
 cp profiles/${tag}* profiles/traffic_* profiles/pmc_latest.json gpurun_out/ 2>/dev/null
+python tools/exp_tail_split.py 2>&1 | grep -v amdgpu.ids > profiles/${tag}_tail_split.txt
+python tools/exp_k8_u8.py 2>&1 | grep -v amdgpu.ids > profiles/${tag}_u8_ingest.txt
+cp profiles/${tag}* gpurun_out/ 2>/dev/null
