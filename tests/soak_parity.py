@@ -32,7 +32,7 @@ def soak_detect(args, rng, t_end, xcorr):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
     from oracle import detect_ref as dr
     from test_detect import make_windows, _margin
-    n_win = n_exact = n_tie = n_bad = n_dyn = 0
+    n_win = n_exact = n_tie = n_bad = n_dyn = n_dyn_floor = 0
     worst = 0.0
     case = 0
     with xcorr.XcorrEngine(2, 4096, 1) as eng:
@@ -53,6 +53,13 @@ def soak_detect(args, rng, t_end, xcorr):
                 rb, rp, rs, rc, rf = ref[w]
                 gb, gp, gs, gc, gf = got[w]
                 ok_floor = abs(gf - rf) < 2e-4
+                if not ok_floor:
+                    # the median of the ORACLE's float32 spectrum is itself that far from a float64 one when a tone 60 dB
+                    # above the floor sets the transform's error (case 3761 of the round-5 soak: oracle 59.688046, float64
+                    # 59.687810, kernel 59.687817): same allowance as for the peak powers below
+                    f64 = float(np.median(20.0 * np.log10(np.abs(np.fft.fft(x[w].astype(np.complex128))) + 1e-12)))
+                    ok_floor = abs(gf - rf) <= 4.0 * abs(float(rf) - f64) + 1e-5
+                    n_dyn_floor += int(ok_floor)
                 if np.array_equal(gb, rb):
                     d = max(float(np.abs(gp - rp).max()) if len(rb) else 0.0, float(np.abs(gs - rs).max()) if len(rb) else 0.0)
                     worst = max(worst, d)
@@ -80,7 +87,8 @@ def soak_detect(args, rng, t_end, xcorr):
                   f"identical={exact} near-tie={tie} bad={bad}{'  FAIL' if bad else ''}", flush=True)
     print(f"SUMMARY (detect): {case} cases, {n_win} windows, {n_exact} identical peak sets, {n_tie} explained by a near-tie (< 1e-3 dB), "
           f"{n_bad} failures, worst dB difference on identical sets {worst:.2e} ({n_dyn} windows beyond 4e-4 dB but within four times the "
-          f"oracle's own float32 error against a float64 spectrum at those bins)")
+          f"oracle's own float32 error against a float64 spectrum at those bins; {n_dyn_floor} noise floors beyond 2e-4 dB but within four "
+          f"times the oracle's own distance to the float64 median)")
     return 1 if n_bad else 0
 
 

@@ -64,7 +64,12 @@ __global__ __launch_bounds__(kThreads, 2) void k_win8k(const void* __restrict__ 
     for (int wl = blockIdx.x; wl < n_win; wl += gridDim.x) {
     C16 sa, sb;      // the two spectra of the next / current pair transform (X_i,h and X_j,h); sample buffers in phase 1
     C16 ev;          // e_0 of the current pair
+#ifdef K8_SHARE   // timing probe (results wrong): workgroups b, b + K8_SHARE, ... use ONE scratch region -- K8_SHARE = 8: all 32
+                  // workgroups of an XCD stream the same 1 MiB (8 buoys) out of their L2
+    const long wbase = (long)(blockIdx.x % K8_SHARE) * B * 2;
+#else
     const long wbase = (long)blockIdx.x * B * 2;                     // this workgroup's scratch: [b][h] x 64 KiB
+#endif
     const long obase = (first_window + wl) * (long)n_pairs;
     int seq = 0, npair = 0, npend = 0;
 
