@@ -35,6 +35,7 @@
 #include "generic_path.hpp"
 #include "win_eo.hpp"
 #include "kwin8k.hpp"                           // N = 8192 on k_win's network, one anchor half resident in LDS (k_win8kl)
+#include "kwin16k.hpp"                          // N = 16384 on the same network: four quarter transforms, two kernels (k16_fwd, k16_pairs)
 #ifdef RMX_EXPERIMENTS
 #include "../../tools/experiments/kwin8k.hpp"   // its two predecessors: parity-green, not faster (LABNOTES.md R4.6)
 #endif
@@ -685,6 +686,9 @@ struct rmx_ctx {
     int g_k8_kind = 1;                     // 1 = k_win8kl (LDS-resident anchor half), 2 = k_win8k (experiments build)
     float4* g_k8_tw1 = nullptr;            // its TW1 tables (both halves)
     float2* g_k8_tw2 = nullptr;            // k_win's TW2 table
+    int g_k16 = 0;                         // N = 16384: k16_fwd + k16_pairs (kwin16k.hpp); 1 = from the measured batch size on, 2 = always
+    float4* g_k16_tw1 = nullptr;           // slot factors of TW1
+    float2 *g_k16_gq = nullptr, *g_k16_tw2 = nullptr, *g_k16_tws = nullptr;   // per-quarter thread factors, k_win's TW2, W_128 rows
     const void* g_cols_inv_fn = nullptr;
     const void* g_cols_fwd_fn[2] = {nullptr, nullptr};   // [u8]
     const void* g_rows_inv_fn = nullptr;
@@ -807,11 +811,13 @@ enum TimeKind {
     kTkFwdSmall = 10,    // g_fwd_small
     kTkPairSmall = 11,   // g_pair_small
     kTkCafSelect = 12,   // k_caf_select / k_caf_select_all
-    kTkCount = 13
+    kTkFwd16k = 13,      // k16_fwd
+    kTkPairs16k = 14,    // k16_pairs
+    kTkCount = 15
 };
 static const char* const kTimeKindName[kTkCount] = {
     "k_fwd", "k_win|k_pair", "g_cols_fwd", "g_rows_fwd", "g_rows_fused", "g_rows_anchor", "g_rows_inv", "g_cols_inv",
-    "g_final", "g_win_*", "g_fwd_small", "g_pair_small", "k_caf_select"};
+    "g_final", "g_win_*", "g_fwd_small", "g_pair_small", "k_caf_select", "k16_fwd", "k16_pairs"};
 static int tm_begin(rmx_ctx* c) {
     if (!c->timing) return RMX_OK;
     const int rc = ensure_events(c, c->ev_used + 2);
@@ -1182,6 +1188,28 @@ static int generic_init(rmx_ctx* c) {
             if (c->g_k8_kind == 2) return fail(c, RMX_E_UNSUPPORTED, "option kwin8k = 2 (k_win8k) exists only in a -DRMX_EXPERIMENTS build");
 #endif
         }
+        // N = 16384: four quarter transforms on the same network, forward and pair kernels per chunk of g_ws_grid windows
+        // (kwin16k.hpp; the spectra of a chunk take the SAME B x 256 KiB per window as g_win_eo15's per-workgroup scratch, so
+        // the buffer is shared).  Option kwin16k: 1 (default) = from the measured batch size on, 2 = every batch, 0 = g_win_eo15.
+        if (c->g_logL == 15 && c->knobs.get_or("kwin16k", 1) != 0 && c->g_ws_upw == 1) {
+            std::vector<float4> t1, t1_4096;
+            std::vector<float2> t2, gq, tws;
+            build_tables(t1_4096, t2);
+            k16::build_tables16k(t1, gq, tws);
+            RMX_HIP(c, hipMalloc((void**)&c->g_k16_tw1, t1.size() * sizeof(float4)));
+            RMX_HIP(c, hipMemcpy(c->g_k16_tw1, t1.data(), t1.size() * sizeof(float4), hipMemcpyHostToDevice));
+            rc = upload(c, &c->g_k16_gq, gq);
+            if (rc) return rc;
+            rc = upload(c, &c->g_k16_tw2, t2);
+            if (rc) return rc;
+            rc = upload(c, &c->g_k16_tws, tws);
+            if (rc) return rc;
+            c->scratch_bytes += t1.size() * sizeof(float4);
+            RMX_HIP(c, hipFuncSetAttribute((const void*)k16::k16_fwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, k16::kLdsFwdBytes));
+            RMX_HIP(c, hipFuncSetAttribute((const void*)k16::k16_fwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, k16::kLdsFwdBytes));
+            RMX_HIP(c, hipFuncSetAttribute((const void*)k16::k16_pairs, hipFuncAttributeMaxDynamicSharedMemorySize, k16::kLdsPairBytes));
+            c->g_k16 = (int)c->knobs.get_or("kwin16k", 1);
+        }
     }
     // windows per chunk (host_plan.hpp: spectra + products under 32 GiB of the 288, "gen_chunk" caps it for experiments)
     const long chunk = host::generic_chunk_windows(c->n_buoys, L, c->max_windows, 32L << 30, c->knobs.get_or("gen_chunk", 0));
@@ -1429,8 +1457,51 @@ static int four_step_windows(rmx_ctx* c, const void* d_iq, int w_first, int n, i
     return RMX_OK;
 }
 
+// N = 16384 through k16_fwd / k16_pairs (kwin16k.hpp): per chunk of g_ws_grid windows (the spectrum scratch holds that many)
+// one forward launch -- (window, buoy) items over at most one workgroup per CU -- and one pair launch of 8 S workgroups,
+// S = workgroups per XCD.  No per-window state survives the chunk.
+static int k16_batch(rmx_ctx* c, const void* d_iq, int n_windows, int n_pairs, int* d_lag, float* d_frac, float* d_peak, bool u8) {
+    const int B = c->n_buoys;
+    const float out_scale = std::ldexp(1.0f, 3 * kTw1ScaleLog2 - 15);
+    const int chunk = c->g_ws_grid;
+    const k16::Pair2* prs = reinterpret_cast<const k16::Pair2*>(c->g_pairs);
+    for (int w0 = 0; w0 < n_windows; w0 += chunk) {
+        const int wc = n_windows - w0 < chunk ? n_windows - w0 : chunk;
+        const int items = wc * B;
+        const unsigned fgrid = (unsigned)(items < c->n_cus ? items : c->n_cus);
+        RMX_TM_BEGIN(c);
+        if (u8)
+            hipLaunchKernelGGL(k16::k16_fwd<true>, dim3(fgrid), dim3(kThreads), k16::kLdsFwdBytes, c->stream, d_iq, c->g_ws_scratch,
+                               c->g_k16_tw1, c->g_k16_gq, c->g_k16_tw2, c->g_k16_tws, (long)w0 * B, items);
+        else
+            hipLaunchKernelGGL(k16::k16_fwd<false>, dim3(fgrid), dim3(kThreads), k16::kLdsFwdBytes, c->stream, d_iq, c->g_ws_scratch,
+                               c->g_k16_tw1, c->g_k16_gq, c->g_k16_tw2, c->g_k16_tws, (long)w0 * B, items);
+        RMX_HIP(c, hipGetLastError());
+        RMX_TM_END(c, kTkFwd16k);
+        const long per_xcd = (long)((wc + 7) / 8) * n_pairs;       // items of the busiest XCD
+        long S = c->n_cus / 8 > 0 ? c->n_cus / 8 : 1;
+        if (per_xcd < S) S = per_xcd;
+        RMX_TM_BEGIN(c);
+        hipLaunchKernelGGL(k16::k16_pairs, dim3((unsigned)(8 * S)), dim3(kThreads), k16::kLdsPairBytes, c->stream, c->g_ws_scratch,
+                           c->g_k16_tw1, c->g_k16_gq, c->g_k16_tw2, c->g_k16_tws, B, prs, n_pairs, (long)w0 * n_pairs, wc, out_scale,
+                           d_lag, d_frac, d_peak);
+        RMX_HIP(c, hipGetLastError());
+        RMX_TM_END(c, kTkPairs16k);
+    }
+    return RMX_OK;
+}
+
 static int generic_batch(rmx_ctx* c, const void* d_iq, int n_windows, int n_pairs, int* d_lag, float* d_frac,
                          float* d_peak, bool u8) {
+    // N = 16384 on k_win's network (kwin16k.hpp): fine-grained items, so no minimum batch for the chip to fill and no partial
+    // last round; wscr = 2 (tests: "the whole-window kernel, whatever the batch") keeps g_win_eo15, as do pair lists beyond
+    // the kernel's LDS copy
+    if (c->g_k16 && c->g_logL == 15 && n_pairs <= k16::kMaxPairs16 &&
+        (c->g_k16 == 2 || (!c->g_wscr_always && n_windows >= (int)c->knobs.get_or("k16_min_windows", 1)))) {
+        const int rc16 = generic_ensure(c, n_pairs, false, false);
+        if (rc16) return rc16;
+        return k16_batch(c, d_iq, n_windows, n_pairs, d_lag, d_frac, d_peak, u8);
+    }
     // g_win_scr runs a window's B + P transforms one after the other in one workgroup: batches that leave most of the chip
     // without a workgroup are better off in the per-transform kernels below (8 buoys x 8 windows of 8192: 0.32 vs 0.05 ms).
     // Measured crossovers (tools/smallw.sh): 0.43 workgroups per CU at L = 16384 (8 buoys; 0.63 with 3), 0.66 .. 0.68 below
@@ -1683,7 +1754,8 @@ void rmx_destroy(rmx_ctx* c) {
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     for (void* p : {(void*)c->g_tw, (void*)c->g_tw1, (void*)c->g_tw2, (void*)c->g_thi, (void*)c->g_tlo, (void*)c->g_spec,
                     (void*)c->g_spec_r, (void*)c->g_prod, (void*)c->g_rec, (void*)c->g_halo, (void*)c->g_pairs,
-                    (void*)c->g_ws_scratch, (void*)c->g_tw_win, (void*)c->g_tw_l, (void*)c->g_k8_tw1, (void*)c->g_k8_tw2})
+                    (void*)c->g_ws_scratch, (void*)c->g_tw_win, (void*)c->g_tw_l, (void*)c->g_k8_tw1, (void*)c->g_k8_tw2,
+                    (void*)c->g_k16_tw1, (void*)c->g_k16_gq, (void*)c->g_k16_tw2, (void*)c->g_k16_tws})
         if (p) (void)hipFree(p);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     for (hipEvent_t e : c->copy_ev)

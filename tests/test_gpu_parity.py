@@ -825,6 +825,24 @@ def test_whole_window_scratch_kernel_by_length(xc, N, B, opts):
             assert all(np.array_equal(x, y) for x, y in zip((ai, af, ap), a8))
             _assert_parity(qi, qf, qp, oi, of_, op)
         xc.clear_default_options()
+    if N == 16384:
+        # the product path of this length since round 5: k16_fwd + k16_pairs (kwin16k.hpp: four quarter transforms on the
+        # fused N = 4096 kernel's network, spectra of a chunk of windows in HBM, the pairs of a window on one XCD); the run
+        # above (wscr = 2) was g_win_eo15
+        xc.clear_default_options()
+        opts("kwin16k", 2)
+        with xc.XcorrEngine(B, N, W) as eng:
+            eng.set_option("timing", 1)
+            ki, kf, kp = eng.correlate(iq)
+            fam = eng.last_timing_by_kernel()
+            k8_ = eng.correlate(raw)
+            qi, qf, qp = eng.correlate(iq[sub], custom)
+        assert set(fam) == {"k16_fwd", "k16_pairs"}, fam
+        _assert_parity(ki[sub], kf[sub], kp[sub], ri, rf, rp, margin, second)
+        assert np.array_equal(ki, li) and np.all(np.abs(kf - lf) <= TOL) and np.allclose(kp, pk, rtol=1e-5)
+        assert all(np.array_equal(x, y) for x, y in zip((ki, kf, kp), k8_))
+        _assert_parity(qi, qf, qp, oi, of_, op)
+        xc.clear_default_options()
     opts("wscr", 0)
     opts("wfused", 0)
     with xc.XcorrEngine(B, N, W) as eng:
@@ -896,9 +914,11 @@ def test_n8192_partial_last_round_through_the_four_step_kernels(xc, opts, B, pai
             assert set(fam2) == {"g_win_*"}                      # forced: no split
 
 
-def test_n16384_partial_last_round_through_the_four_step_kernels(xc, opts):
-    """The same for g_win_eo15 (N = 16384, buoy_node.py:364): W = CUs + 24 windows of 5 buoys -- the 24 windows of the partial
-    round through the four-step kernels; against the oracle on both parts, integer lags equal to the all-g_win_eo15 run."""
+def test_n16384_more_windows_than_one_chunk(xc, opts):
+    """N = 16384 (buoy_node.py:364), W = CUs + 24 windows of 5 buoys.  Default: k16_fwd / k16_pairs in two chunks (the spectrum
+    scratch holds one window per CU), every window of the second chunk and a few of the first against the oracle.  Option
+    kwin16k = 0: g_win_eo15 takes the full round and the 24 windows of the partial round go through the four-step kernels
+    (round 5's cost model); integer lags equal, and equal to the all-g_win_eo15 run (wscr = 2)."""
     N, B = 16384, 5
     W = _device_cus() + 24
     iq = rm.synth.make_windows(W, B, N, 2.4e6, seed=515)[0]
@@ -908,12 +928,98 @@ def test_n16384_partial_last_round_through_the_four_step_kernels(xc, opts):
         eng.set_option("timing", 1)
         li, lf, pk = eng.correlate(iq)
         fam = eng.last_timing_by_kernel()
-    assert fam["g_win_*"]["launches"] == 1 and "g_cols_inv" in fam, fam
+    assert set(fam) == {"k16_fwd", "k16_pairs"} and fam["k16_fwd"]["launches"] == 2 and fam["k16_pairs"]["launches"] == 2, fam
     _assert_parity(li[chk], lf[chk], pk[chk], ri, rf, rp)
+    opts("kwin16k", 0)
+    with xc.XcorrEngine(B, N, W) as eng:
+        eng.set_option("timing", 1)
+        ei, ef, ep = eng.correlate(iq)
+        fam = eng.last_timing_by_kernel()
+    assert fam["g_win_*"]["launches"] == 1 and "g_cols_inv" in fam, fam
+    assert np.array_equal(ei, li) and np.all(np.abs(ef - lf) <= TOL) and np.allclose(ep, pk, rtol=1e-5)
     opts("wscr", 2)
     with xc.XcorrEngine(B, N, W) as eng:
         ai, af, ap = eng.correlate(iq)
     assert np.array_equal(ai, li) and np.all(np.abs(af - lf) <= TOL) and np.allclose(ap, pk, rtol=1e-5)
+
+
+@pytest.mark.parametrize("B,W", [(3, 1), (8, 1), (2, 7), (16, 2), (5, 9), (3, 40)])
+def test_n16384_small_batches_through_the_quarter_kernels(xc, B, W):
+    """k16_fwd / k16_pairs have no minimum batch: (window, buoy) and (window, pair) items spread over the chip whatever the
+    number of windows (one window of 3 buoys: 3 forward and 3 pair workgroups; 7 windows: XCDs with one window and XCDs
+    with none).  Default options, complex64 and raw uint8, against the oracle."""
+    N = 16384
+    iq, _, raw = rm.synth.make_windows(W, B, N, 2.4e6, seed=1600 + 10 * B + W, return_u8=True)
+    ri, rf, rp = orc.xcorr_batch_fast(iq[:12], workers=8)
+    with xc.XcorrEngine(B, N, W) as eng:
+        eng.set_option("timing", 1)
+        li, lf, pk = eng.correlate(iq)
+        fam = eng.last_timing_by_kernel()
+        l8 = eng.correlate(raw)
+    assert set(fam) == {"k16_fwd", "k16_pairs"}, fam
+    _assert_parity(li[:12], lf[:12], pk[:12], ri, rf, rp)
+    assert all(np.array_equal(x, y) for x, y in zip((li, lf, pk), l8))
+
+
+@pytest.mark.parametrize("kwin16k", [2, 0])
+def test_edge_cases_n16384(xc, opts, kwin16k):
+    """The edge windows of test_edge_cases_n4096 at the reference's capture length (buoy_node.py:364) through k16_pairs
+    (kwin16k = 2) and g_win_eo15 (kwin16k = 0, wscr = 2): zeros (every lag ties -> the lowest index, the kernels' exact-tie
+    path through both search phases of k16_pairs), impulses, peaks on both edges (the two ends of the quarter-butterfly's
+    output order), two peaks of equal height, constant inputs; raw-order custom list with the mirror pair."""
+    N = 16384
+    e = np.zeros((7, 2, N), np.complex64)
+    e[1, 0, 5] = 1.0; e[1, 1, 25] = 2.0 - 1.0j
+    e[2, 0, 0] = 3.0; e[2, 1, N - 1] = 1.0j
+    e[3, 0, N - 1] = 1.0; e[3, 1, 0] = -2.0
+    e[4, 0, 100] = 1.0; e[4, 1, 93] = 1.0; e[4, 1, 109] = 1.0
+    e[5, 0, :] = 4.5 - 2.5j; e[5, 1, :] = -1.5 + 0.5j
+    e[6, 0, 9000] = 1.0; e[6, 1, 808] = 1.0 + 1.0j            # lag -8192: the seam between two quarters of the output
+    ri, rf, rp = orc.xcorr_batch_literal(e)
+    opts("kwin16k", kwin16k)
+    if kwin16k == 0:
+        opts("wscr", 2)
+    with xc.XcorrEngine(2, N, 7) as eng:
+        li, lf, pk = eng.correlate(e)
+        both = eng.correlate(e, pairs=np.array([[0, 1], [1, 0], [0, 1]], np.int32))
+    assert li[0, 0] == -(N - 1) and lf[0, 0] == 0.0 and pk[0, 0] == 0.0      # all ties -> lowest index
+    assert li[1, 0] == ri[1, 0] == 20
+    assert li[2, 0] == ri[2, 0] == N - 1 and lf[2, 0] == 0.0
+    assert li[3, 0] == ri[3, 0] == -(N - 1) and lf[3, 0] == 0.0
+    margin4, first4, second4 = orc.peak_top2(e[4, 0], e[4, 1])
+    assert {first4, second4} == {-7, 9} and margin4 <= TOL and li[4, 0] in (first4, second4)
+    cond = float(rp[5, 0]) / abs(2.0 * float(rp[5, 0]) / N)
+    assert li[5, 0] == ri[5, 0] == 0 and abs(lf[5, 0] - rf[5, 0]) <= max(TOL, 4 * 6e-8 * cond)
+    assert li[6, 0] == ri[6, 0] == -8192 and abs(lf[6, 0] - rf[6, 0]) <= TOL
+    assert np.allclose(pk[1:], rp[1:], rtol=1e-5)
+    assert np.array_equal(both[0][:, 0], li[:, 0]) and np.array_equal(both[0][:, 2], li[:, 0])
+    assert np.array_equal(both[0][[1, 2, 3, 5, 6], 1], -li[[1, 2, 3, 5, 6], 0]) and both[0][0, 1] == -(N - 1)
+
+
+def test_n16384_pair_lists_beyond_the_lds_copy(xc):
+    """k16_pairs keeps the pair list in LDS (640 entries); a longer one takes the earlier kernels.  700 pairs (repeats, both
+    orders) on 4 buoys x 20 windows against the oracle's answer for the 12 distinct ordered pairs; the first 600 alone
+    through k16_pairs."""
+    N, B, W = 16384, 4, 20
+    iq = rm.synth.make_windows(W, B, N, 2.4e6, seed=62)[0]
+    rng = np.random.default_rng(10)
+    a = rng.integers(0, B, size=700)
+    b = (a + rng.integers(1, B, size=700)) % B
+    pairs = np.stack([a, b], axis=1).astype(np.int32)
+    distinct = np.array([(i, j) for i in range(B) for j in range(B) if i != j], np.int32)
+    ri, rf, rp = orc.xcorr_batch_fast(iq[:6], distinct, workers=8)
+    col = {(int(i), int(j)): k for k, (i, j) in enumerate(distinct)}
+    idx = np.array([col[(int(i), int(j))] for i, j in pairs])
+    with xc.XcorrEngine(B, N, W) as eng:
+        eng.set_option("timing", 1)
+        li, lf, pk = eng.correlate(iq, pairs)
+        fam_long = eng.last_timing_by_kernel()
+        si, sf, sp = eng.correlate(iq, pairs[:600])
+        fam_short = eng.last_timing_by_kernel()
+    assert "k16_pairs" not in fam_long and set(fam_short) == {"k16_fwd", "k16_pairs"}, (fam_long, fam_short)
+    _assert_parity(li[:6], lf[:6], pk[:6], ri[:, idx], rf[:, idx], rp[:, idx])
+    _assert_parity(si[:6], sf[:6], sp[:6], ri[:, idx[:600]], rf[:, idx[:600]], rp[:, idx[:600]])
+    assert np.array_equal(li[:, :600], si) and np.all(np.abs(lf[:, :600] - sf) <= TOL)
 
 
 def test_n8192_pair_lists_beyond_the_lds_copy(xc, opts):
