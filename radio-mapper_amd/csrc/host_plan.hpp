@@ -52,7 +52,7 @@ inline const std::vector<OptionSpec>& option_specs() {
         {"cols_threads", 64, 1024, "four-step: threads per column tile"},
         {"col_logt", 3, 5, "four-step: log2 columns per tile"},
         {"kwin16k", 0, 2, "N = 16384: 1 (default) k16_fwd + k16_pairs (four quarter transforms on the fused N = 4096 network) unless wscr = 2, 2 always, 0 g_win_eo15 / the four-step kernels"},
-        {"k16_min_windows", 1, 1 << 30, "kwin16k = 1: smallest batch that takes k16_fwd / k16_pairs"},
+        {"k16_min_windows", 1, 1 << 30, "kwin16k = 1: smallest batch that takes k16_fwd / k16_pairs (default: 100 / (buoys + pairs), rounded up)"},
         {"kwin8k", 0, 2, "N = 8192, batches that fill the chip: 1 (default) k_win8kl (the bin-parity halves on the fused N = 4096 network, one anchor half in LDS), 0 g_win_scr14, 2 k_win8k (-DRMX_EXPERIMENTS builds only)"},
 #ifdef RMX_EXPERIMENTS
         {"pk", 0, 1, "1: k_winp (packed fp32 build of the fused kernel; -DRMX_EXPERIMENTS builds only)"},

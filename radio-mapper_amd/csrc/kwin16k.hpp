@@ -288,7 +288,8 @@ __global__ __launch_bounds__(kThreads, 2) void k16_pairs(const float4* __restric
                                                         int n_buoys,
                                                         const Pair2* __restrict__ pairs, int n_pairs,
                                                         long out_first,       // output index of (window 0, pair 0)
-                                                        int n_win, float out_scale, int* __restrict__ lag_int,
+                                                        int n_win, int flat,  // flat: items b, b + grid, ... of [(window 0, pair 0 .. P-1), (window 1, ...)]
+                                                        float out_scale, int* __restrict__ lag_int,
                                                         float* __restrict__ lag_frac, float* __restrict__ peak) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2* img0 = reinterpret_cast<float2*>(smem);
@@ -307,10 +308,11 @@ __global__ __launch_bounds__(kThreads, 2) void k16_pairs(const float4* __restric
 
     // this workgroup's items: XCD x = blockIdx mod 8 owns the windows x, x + 8, ...; its workgroups s = 0 .. S-1 take the
     // items s, s + S, ... of [(window, pair 0 .. P-1), (window + 8, ...), ...]
-    const int xcd = blockIdx.x & 7, S = gridDim.x >> 3;
-    const int nwx = n_win > xcd ? (n_win - xcd + 7) >> 3 : 0;
+    // (flat: fewer windows than would keep eight XCDs evenly busy -- one window of 16 buoys is 120 items for ONE XCD otherwise)
+    const int xcd = flat ? 0 : blockIdx.x & 7, S = flat ? gridDim.x : gridDim.x >> 3, wstep = flat ? 1 : 8;
+    const int nwx = flat ? n_win : (n_win > xcd ? (n_win - xcd + 7) >> 3 : 0);
     const long n_it = (long)nwx * P;
-    long it = blockIdx.x >> 3;
+    long it = flat ? blockIdx.x : blockIdx.x >> 3;
     if (it >= n_it) return;
 
     load_tw2_to_lds_grouped(tw2_lds, tw2_g, t);
@@ -428,7 +430,7 @@ __global__ __launch_bounds__(kThreads, 2) void k16_pairs(const float4* __restric
     };
 
     // ---- the item loop
-    int wl = xcd + 8 * (int)(it / P);          // window of the current item, pair index
+    int wl = xcd + wstep * (int)(it / P);      // window of the current item, pair index
     int pq = (int)(it % P);
     auto all_parts = [&](C16& d, const __amdgpu_buffer_rsrc_t& rs, int sidx) __attribute__((always_inline)) {
         load_part(d, rs, sidx, std::integral_constant<int, 0>{}); load_part(d, rs, sidx, std::integral_constant<int, 1>{});
@@ -445,7 +447,7 @@ __global__ __launch_bounds__(kThreads, 2) void k16_pairs(const float4* __restric
     for (; it < n_it; it += S) {
         // the item behind this one (behind the last: this one again -- indices that exist, results unused)
         int wn = wl, qn = pq + S;
-        while (qn >= P) { qn -= P; wn += 8; }
+        while (qn >= P) { qn -= P; wn += wstep; }
         const bool has_next = it + S < n_it;
         if (!has_next) { wn = wl; qn = pq; }
         const int2 prc = reinterpret_cast<const int2*>(plist)[pq];

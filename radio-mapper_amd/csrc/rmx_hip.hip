@@ -1478,13 +1478,18 @@ static int k16_batch(rmx_ctx* c, const void* d_iq, int n_windows, int n_pairs, i
                                c->g_k16_tw1, c->g_k16_gq, c->g_k16_tw2, c->g_k16_tws, (long)w0 * B, items);
         RMX_HIP(c, hipGetLastError());
         RMX_TM_END(c, kTkFwd16k);
+        // XCD-aware item order (the pairs of a window on one XCD) unless the windows do not spread evenly over eight XCDs
+        // and are few: 9 windows would give XCD 0 two windows' work and leave the batch waiting for it
+        const int flat = (wc < 32 && wc % 8 != 0) || c->n_cus < 8 ? 1 : 0;
         const long per_xcd = (long)((wc + 7) / 8) * n_pairs;       // items of the busiest XCD
         long S = c->n_cus / 8 > 0 ? c->n_cus / 8 : 1;
         if (per_xcd < S) S = per_xcd;
+        long pgrid = 8 * S;
+        if (flat) pgrid = (long)wc * n_pairs < c->n_cus ? (long)wc * n_pairs : c->n_cus;
         RMX_TM_BEGIN(c);
-        hipLaunchKernelGGL(k16::k16_pairs, dim3((unsigned)(8 * S)), dim3(kThreads), k16::kLdsPairBytes, c->stream, c->g_ws_scratch,
-                           c->g_k16_tw1, c->g_k16_gq, c->g_k16_tw2, c->g_k16_tws, B, prs, n_pairs, (long)w0 * n_pairs, wc, out_scale,
-                           d_lag, d_frac, d_peak);
+        hipLaunchKernelGGL(k16::k16_pairs, dim3((unsigned)pgrid), dim3(kThreads), k16::kLdsPairBytes, c->stream, c->g_ws_scratch,
+                           c->g_k16_tw1, c->g_k16_gq, c->g_k16_tw2, c->g_k16_tws, B, prs, n_pairs, (long)w0 * n_pairs, wc, flat,
+                           out_scale, d_lag, d_frac, d_peak);
         RMX_HIP(c, hipGetLastError());
         RMX_TM_END(c, kTkPairs16k);
     }
@@ -1493,11 +1498,13 @@ static int k16_batch(rmx_ctx* c, const void* d_iq, int n_windows, int n_pairs, i
 
 static int generic_batch(rmx_ctx* c, const void* d_iq, int n_windows, int n_pairs, int* d_lag, float* d_frac,
                          float* d_peak, bool u8) {
-    // N = 16384 on k_win's network (kwin16k.hpp): fine-grained items, so no minimum batch for the chip to fill and no partial
-    // last round; wscr = 2 (tests: "the whole-window kernel, whatever the batch") keeps g_win_eo15, as do pair lists beyond
-    // the kernel's LDS copy
+    // N = 16384 on k_win's network (kwin16k.hpp): fine-grained items, so no partial last round and a low minimum batch -- its
+    // two launches cost about 40 us whatever the size, the four-step kernels 26 us for one window: from about 100 transforms
+    // (windows x (buoys + pairs)) on it wins (tools/exp_k16_sweep.py: 3 buoys from 16 windows, 5 from 8, 8 from 1).  wscr = 2
+    // (tests: "the whole-window kernel, whatever the batch") keeps g_win_eo15, as do pair lists beyond the kernel's LDS copy
     if (c->g_k16 && c->g_logL == 15 && n_pairs <= k16::kMaxPairs16 &&
-        (c->g_k16 == 2 || (!c->g_wscr_always && n_windows >= (int)c->knobs.get_or("k16_min_windows", 1)))) {
+        (c->g_k16 == 2 || (!c->g_wscr_always &&
+                           n_windows >= (int)c->knobs.get_or("k16_min_windows", (100 + c->n_buoys + n_pairs - 1) / (c->n_buoys + n_pairs))))) {
         const int rc16 = generic_ensure(c, n_pairs, false, false);
         if (rc16) return rc16;
         return k16_batch(c, d_iq, n_windows, n_pairs, d_lag, d_frac, d_peak, u8);

@@ -88,8 +88,11 @@ def test_golden_fixtures_other_lengths(xc, golden_dir, name, opts):
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     iq = orc.decode_u8_iq(g["raw_u8"])
     W, B, N = iq.shape
-    for force in (False, True):
-        if force:
+    for force in (False, True) + (("k16",) if N == 16384 else ()):
+        if force == "k16":            # N = 16384 from about a hundred transforms per batch on: k16_fwd + k16_pairs (kwin16k.hpp)
+            xc.clear_default_options()
+            opts("kwin16k", 2)
+        elif force:
             opts("wscr", 2)
         with xc.XcorrEngine(B, N, W) as eng:
             li, lf, pk = eng.correlate(iq)
@@ -943,14 +946,17 @@ def test_n16384_more_windows_than_one_chunk(xc, opts):
     assert np.array_equal(ai, li) and np.all(np.abs(af - lf) <= TOL) and np.allclose(ap, pk, rtol=1e-5)
 
 
-@pytest.mark.parametrize("B,W", [(3, 1), (8, 1), (2, 7), (16, 2), (5, 9), (3, 40)])
-def test_n16384_small_batches_through_the_quarter_kernels(xc, B, W):
-    """k16_fwd / k16_pairs have no minimum batch: (window, buoy) and (window, pair) items spread over the chip whatever the
-    number of windows (one window of 3 buoys: 3 forward and 3 pair workgroups; 7 windows: XCDs with one window and XCDs
-    with none).  Default options, complex64 and raw uint8, against the oracle."""
+@pytest.mark.parametrize("B,W", [(3, 1), (8, 1), (2, 7), (16, 2), (5, 9), (3, 40), (4, 33)])
+def test_n16384_small_batches_through_the_quarter_kernels(xc, opts, B, W):
+    """k16_fwd / k16_pairs on batches far below a chip-full (option kwin16k = 2): (window, buoy) and (window, pair) items
+    spread over the chip whatever the number of windows -- one window of 3 buoys: 3 forward and 3 pair workgroups; fewer than
+    32 windows that are no multiple of 8: the flat item order instead of the XCD-aware one; 33 windows: XCD 0 with five
+    windows, the others with four.  complex64 and raw uint8 against the oracle.  With default options the same batch takes
+    these kernels from about 100 transforms (windows x (buoys + pairs)) on and the four-step kernels below."""
     N = 16384
     iq, _, raw = rm.synth.make_windows(W, B, N, 2.4e6, seed=1600 + 10 * B + W, return_u8=True)
     ri, rf, rp = orc.xcorr_batch_fast(iq[:12], workers=8)
+    opts("kwin16k", 2)
     with xc.XcorrEngine(B, N, W) as eng:
         eng.set_option("timing", 1)
         li, lf, pk = eng.correlate(iq)
@@ -959,6 +965,13 @@ def test_n16384_small_batches_through_the_quarter_kernels(xc, B, W):
     assert set(fam) == {"k16_fwd", "k16_pairs"}, fam
     _assert_parity(li[:12], lf[:12], pk[:12], ri, rf, rp)
     assert all(np.array_equal(x, y) for x, y in zip((li, lf, pk), l8))
+    xc.clear_default_options()
+    with xc.XcorrEngine(B, N, W) as eng:
+        eng.set_option("timing", 1)
+        di, df, dp = eng.correlate(iq)
+        fam = eng.last_timing_by_kernel()
+    assert ("k16_pairs" in fam) == (W * (B + B * (B - 1) // 2) >= 100), fam
+    assert np.array_equal(di, li) and np.all(np.abs(df - lf) <= TOL) and np.allclose(dp, pk, rtol=1e-5)
 
 
 @pytest.mark.parametrize("kwin16k", [2, 0])

@@ -3,7 +3,7 @@
 // integer lag against the generator and prints ms per batch + fraction of the 8 TB/s algorithmic roofline.
 //   build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -mllvm -simplifycfg-sink-common=false -Wno-inline-asm \
 //          -I../../radio-mapper_amd/csrc -o k16_bench k16_bench.hip
-//   run:   k16_bench [B=8] [W=256] [reps=50] [chunk=64] [pair grid per XCD S=32]
+//   run:   k16_bench [B=8] [W=256] [reps=50] [chunk=64] [pair grid per XCD S=32] [warm-up launches=20]
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -40,6 +40,7 @@ int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 8, W = argc > 2 ? atoi(argv[2]) : 256, reps = argc > 3 ? atoi(argv[3]) : 50;
     int chunk = argc > 4 ? atoi(argv[4]) : 64;
     const int S = argc > 5 ? atoi(argv[5]) : 32;
+    const int warm = argc > 6 ? atoi(argv[6]) : 20;      // (counter runs: 1)
     if (chunk > W) chunk = W;
     const int N = k16::kN16, P = B * (B - 1) / 2;
     float2* iq; float4 *spec, *tw1; float2 *tw2, *tws, *gq; int* li; float *lf, *pk; k16::Pair2* prs;
@@ -77,12 +78,12 @@ int main(int argc, char** argv) {
             long per_xcd = (long)((wc + 7) / 8) * P;
             const int s = per_xcd < S ? (int)per_xcd : S;
             hipLaunchKernelGGL(k16::k16_pairs, dim3(8 * s), dim3(kThreads), k16::kLdsPairBytes, 0, spec, tw1, gq, tw2, tws, B, prs, P,
-                               (long)w0 * P, wc, out_scale, li, lf, pk);
+                               (long)w0 * P, wc, 0, out_scale, li, lf, pk);
         }
     };
     for (int round = 0; round < 2; ++round) {
         CK(hipMemset(li, 0xff, (size_t)W * P * 4));
-        for (int i = 0; i < (round ? 5 : 20); ++i) launch(false);
+        for (int i = 0; i < (round ? (warm < 5 ? warm : 5) : warm); ++i) launch(false);
         CK(hipDeviceSynchronize());
         CK(hipGetLastError());
         CK(hipEventRecord(e0));
@@ -93,7 +94,7 @@ int main(int argc, char** argv) {
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         ms /= reps;
         fwd_ms = 0.0f; fwd_n = 0;
-        for (int i = 0; i < 5; ++i) launch(true);
+        for (int i = 0; i < (warm < 5 ? 1 : 5); ++i) launch(true);
         CK(hipDeviceSynchronize());
         std::vector<int> h((size_t)W * P);
         CK(hipMemcpy(h.data(), li, h.size() * 4, hipMemcpyDeviceToHost));
@@ -121,7 +122,7 @@ int main(int argc, char** argv) {
         const double alg = (double)W * P * (16.0 * N + 12.0);
         printf("[%d] k16 B=%d W=%d chunk=%d S=%d  %.4f ms  frac %.4f  (forward kernels %.4f ms of it) | us per quarter transform and CU %.3f | "
                "lags != generator %ld of %ld | frac[0] %.5f peak[0] %.3f | fnv %016llx\n",
-               round, B, W, chunk, S, ms, alg / (ms * 1e-3) / 8e12, fwd_ms / 5.0f, ms * 1e3 * 256.0 / ((double)W * 4.0 * (B + P)), bad, (long)W * P,
+               round, B, W, chunk, S, ms, alg / (ms * 1e-3) / 8e12, fwd_ms / (warm < 5 ? 1.0f : 5.0f), ms * 1e3 * 256.0 / ((double)W * 4.0 * (B + P)), bad, (long)W * P,
                hf[0], hpk[0], hsum);
         fflush(stdout);
     }

@@ -6,11 +6,13 @@ out=$PWD/gpurun_out/${K16_PMC_OUT:-pmc_k16}
 rm -rf "$out"; mkdir -p "$out"
 export TMPDIR=/tmp
 BIN=${K16_BIN:-$PWD/tools/probe/k16_bench}
-args=${@:-8 256 4 256 32}
+args=${@:-8 256 1 256 32 1}
 cd /tmp
 i=0
-for set in "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_BUBBLE_sum" \
+for set in "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" \
+           "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_BUBBLE_sum" \
            "TCC_EA0_RDREQ_DRAM_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_TAG_STALL_sum" \
+           "TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum" \
            "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_INSTS_VALU" \
            "SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU"; do
   i=$((i+1))
