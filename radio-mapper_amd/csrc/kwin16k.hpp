@@ -268,7 +268,10 @@ __global__ __launch_bounds__(kThreads, 2) void k16_fwd(const void* __restrict__ 
                 asm volatile("" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3));
                 const u32x4 w = {__float_as_uint(e0), __float_as_uint(e1), __float_as_uint(e2), __float_as_uint(e3)};
 #ifndef K16_NO_STORE
-                __builtin_amdgcn_raw_buffer_store_b128(w, ss, soff + (h * 8 + j) * (kThreads * 16), 0, 0);
+#ifndef K16_STORE_AUX
+#define K16_STORE_AUX 0
+#endif
+                __builtin_amdgcn_raw_buffer_store_b128(w, ss, soff + (h * 8 + j) * (kThreads * 16), 0, K16_STORE_AUX);
 #else
                 if (e0 == 12345.678f) __builtin_amdgcn_raw_buffer_store_b128(w, ss, soff + (h * 8 + j) * (kThreads * 16), 0, 0);
 #endif

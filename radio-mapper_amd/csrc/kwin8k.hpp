@@ -163,7 +163,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_win8kl(const void* __restrict__
                                                        const Pair2* __restrict__ pairs, int n_pairs, long first_window,
                                                        float out_scale, int* __restrict__ lag_int,
                                                        float* __restrict__ lag_frac, float* __restrict__ peak, int n_win,
-                                                       int stag) {
+                                                       int stag) {   // (stag: unused here -- one exchange image, no half-order staggering; kept so the launch sites of the three N = 8192 kernels match)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2* img0 = reinterpret_cast<float2*>(smem);                      // the ONE exchange image
     float4* anc = reinterpret_cast<float4*>(smem + kLdsLAnc);            // anchor half 1: [8][512] float4, thread-private columns
@@ -450,39 +450,46 @@ __global__ __launch_bounds__(kThreads, 2) void k_win8kl(const void* __restrict__
         for (int j = 0; j < 8; ++j) anc[j * kThreads + t] = make_float4(ev.re[2 * j], ev.im[2 * j], ev.re[2 * j + 1], ev.im[2 * j + 1]);
     };
 
-    // ---- forward transform of half h of buoy b from its samples in pa / pb (both halves of a buoy from ONE load: the 32
-    // eight-byte requests per thread -- lane pairs ask for the same sample -- are a visible part of a forward transform) into
-    // x, in registers.  `lead`: a barrier in front of the role-A stores (the transform before was a forward one too: some
+    // ---- forward transform of half h of buoy b.  A buoy's samples arrive in pa / pb (x[n], x[n + 4096]: lane pairs ask for
+    // the same sample); fold_both() turns them into the two halves' folded inputs in place, fwd_half(h) transforms one into x,
+    // in registers.  `lead`: a barrier in front of the role-A stores (the transform before was a forward one too: some
     // wave may still be at its wave-local reads; behind a pair transform its second barrier already says so).  `swap_tw1`:
-    // request the other half's TW1 table behind the use of this one (no pair transform of this half follows).  `nb` >= 0:
-    // request buoy nb's samples behind the fold (the sample registers are free behind a buoy's SECOND fold).
+    // request the other half's TW1 table behind the use of this one (no pair transform of this half follows).  `nb`:
+    // the buoy whose samples of this half are requested behind the copy into x.
     C16 pa, pb;
-    auto fwd_half = [&](auto hc, float2 (&x)[16], bool lead, bool swap_tw1, int nb) __attribute__((always_inline)) {
-        constexpr int h = decltype(hc)::value;
-        if constexpr (h == 0) {
+    // both folds of a buoy at once, in place: pa <- a + (-1)^p b (half 0), pb <- a + (-1)^p (-i) b (half 1)
+    auto fold_both = [&]() __attribute__((always_inline)) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) x[q] = make_float2(fmaf(sgn, pb.re[q], pa.re[q]), fmaf(sgn, pb.im[q], pa.im[q]));
-        } else {   // a + (-1)^p (-i) b
-#pragma unroll
-            for (int q = 0; q < 16; ++q) x[q] = make_float2(fmaf(sgn, pb.im[q], pa.re[q]), fmaf(-sgn, pb.re[q], pa.im[q]));
+        for (int q = 0; q < 16; ++q) {
+            const float ar = pa.re[q], ai = pa.im[q], br = pb.re[q], bi = pb.im[q];
+            pa.set(q, fmaf(sgn, br, ar), fmaf(sgn, bi, ai));
+            pb.set(q, fmaf(sgn, bi, ar), fmaf(-sgn, br, ai));
         }
         // (opaque from here on: the uint8 and the complex64 build must run the SAME arithmetic on these values)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) asm volatile("" : "+v"(pa.re[q]), "+v"(pa.im[q]), "+v"(pb.re[q]), "+v"(pb.im[q]));
+    };
+    auto fwd_half = [&](auto hc, float2 (&x)[16], bool lead, bool swap_tw1, int nb) __attribute__((always_inline)) {
+        constexpr int h = decltype(hc)::value;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) x[q] = h == 0 ? pa.get(q) : pb.get(q);
 #pragma unroll
         for (int q = 0; q < 16; q += 4)
             asm volatile("" : "+v"(x[q].x), "+v"(x[q].y), "+v"(x[q + 1].x), "+v"(x[q + 1].y), "+v"(x[q + 2].x),
                          "+v"(x[q + 2].y), "+v"(x[q + 3].x), "+v"(x[q + 3].y));
-        if constexpr (h == 1) {
-            // The next buoy's samples travel from here on (the sample registers are free behind a buoy's second fold).
-            // UNCONDITIONAL requests (behind the last buoy: its own samples once more, into dead registers): hipcc merges a
-            // condition around them with the loop's exit test and sinks them to the loop latch, where the next fold waits.
-            // (Requested only at the END of this transform -- 64 fewer live registers during it -- measured 3 % slower.)
+        // The folded half is in x: its sample registers are free, and the next buoy's samples of THAT half travel from here
+        // on -- 16 requests per half transform (all 32 behind the second fold: 3 % slower at 3 and 8 buoys, the burst hits
+        // every CU of the chip at the same time).  UNCONDITIONAL requests (behind the last buoy: its own samples once more,
+        // into dead registers): hipcc merges a condition around them with the loop's exit test and sinks them to the loop
+        // latch, where the next fold waits.
 #ifndef K8_NO_SAMPLE
+        {
             const int nbu = __builtin_amdgcn_readfirstlane(nb);
-            load_x(pa, nbu, 0);
-            load_x(pb, nbu, kN8 / 2);
+            if constexpr (h == 0) load_x(pa, nbu, 0);
+            else load_x(pb, nbu, kN8 / 2);
             __builtin_amdgcn_sched_barrier(0);
-#endif
         }
+#endif
         twist(x, h);
         dft16(x);
         mul_tw1(x, tw1);
@@ -518,7 +525,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_win8kl(const void* __restrict__
         float2 x[16];
         cvt_x(pa);
         cvt_x(pb);
-        fwd_half(std::integral_constant<int, 0>{}, x, true, true, 0);
+        fold_both();
+        fwd_half(std::integral_constant<int, 0>{}, x, true, true, 1);
 #pragma unroll
         for (int q = 0; q < 16; ++q) sa.set(q, x[q].x, x[q].y);
         fwd_half(std::integral_constant<int, 1>{}, x, true, true, 1);
@@ -528,8 +536,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_win8kl(const void* __restrict__
             float2 v[16];
             cvt_x(pa);
             cvt_x(pb);
+            fold_both();
             // ---- half 0: X_j,0, stored for the later anchors, and e_0 of (0, j)
-            fwd_half(std::integral_constant<int, 0>{}, x, j == 1, false, 0);
+            fwd_half(std::integral_constant<int, 0>{}, x, j == 1, false, j + 1 < B ? j + 1 : j);
 #ifndef K8_NO_STORE
             store_spec(x, 2 * j);
 #endif
@@ -557,7 +566,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_win8kl(const void* __restrict__
             float2 x[16];
             cvt_x(pa);
             cvt_x(pb);
-            fwd_half(std::integral_constant<int, 0>{}, x, true, true, 0);
+            fold_both();
+            fwd_half(std::integral_constant<int, 0>{}, x, true, true, b + 1 < B ? b + 1 : b);
 #ifndef K8_NO_STORE
             store_spec(x, 2 * b);
 #endif

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""GPU box: the partial last round of the whole-window kernels (k_win8kl at N = 8192, g_win_eo15 at N = 16384) through the
-four-step kernels (default dispatch) against the whole-window kernel for every window (option wscr = 2): us per call, results equal?"""
+"""GPU box: the partial last round of the whole-window kernels (k_win8kl at N = 8192; g_win_eo15 at N = 16384, i.e. option
+kwin16k = 0 since k16_fwd / k16_pairs became that length's default) through the four-step kernels against the whole-window
+kernel for every window (option wscr = 2): us per call, results equal?  At N = 16384 a third column: the default dispatch."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -18,7 +19,7 @@ for N, B, W in shapes:
     x = torch.stack([src[:, 0, s:s + N] for s in sh], dim=1).contiguous() + torch.randn((W, B, N, 2), device=dev, generator=g) * 10.0
     P = B * (B - 1) // 2
     res, outs = [], []
-    for opt in ({}, {"wscr": 2}):
+    for opt in (({"kwin16k": 0}, {"wscr": 2, "kwin16k": 0}, {}) if N == 16384 else ({}, {"wscr": 2})):
         xcorr.clear_default_options()
         for k, v in opt.items():
             xcorr.set_default_option(k, v)
@@ -42,5 +43,6 @@ for N, B, W in shapes:
         outs.append((lag.cpu().numpy().copy(), fr.cpu().numpy().copy()))
     xcorr.clear_default_options()
     same = int(np.sum(outs[0][0] != outs[1][0]))
-    print(f"N={N} B={B:2d} W={W}: default {res[0][0] * 1e3:8.1f} us ({'split' if len(res[0][1]) > 1 else 'whole'})   whole-window kernel only {res[1][0] * 1e3:8.1f} us   "
-          f"lag_int differ {same}, max |dfrac| {np.abs(outs[0][1] - outs[1][1]).max():.1e}", flush=True)
+    print(f"N={N} B={B:2d} W={W}: split dispatch {res[0][0] * 1e3:8.1f} us ({'split' if len(res[0][1]) > 1 else 'whole'})   whole-window kernel only {res[1][0] * 1e3:8.1f} us   "
+          f"lag_int differ {same}, max |dfrac| {np.abs(outs[0][1] - outs[1][1]).max():.1e}"
+          + (f"   k16_fwd + k16_pairs (the default) {res[2][0] * 1e3:8.1f} us, lag_int differ {int(np.sum(outs[2][0] != outs[1][0]))}" if len(res) > 2 else ""), flush=True)
