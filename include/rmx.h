@@ -114,7 +114,9 @@ int rmx_set_option(rmx_ctx* ctx, const char* key, long value);
  * library never reads the environment.  Keys (radio-mapper_amd/csrc/host_plan.hpp lists ranges and meanings):
  * "stag", "ncus", "chunk_windows", "small4096", "generic4096", "small_maxl", "logl1", "wfused", "wscr", "wscr14",
  * "wscr_per_cu", "rows_anchor", "fused", "fused_def", "gen_chunk", "rows_tpr", "cols_threads", "col_logt", "kwin8k"
- * (N = 8192, batches that fill the chip: 1 = k_win8kl, the default; 0 = g_win_scr14).
+ * (N = 8192, batches that fill the chip: 1 = k_win8kl, the default; 0 = g_win_scr14), "kwin16k" (N = 16384: 1 = k16_fwd +
+ * k16_pairs from "k16_min_windows" windows on -- default 100 / (buoys + pairs) -- unless "wscr" = 2; 2 = for every batch;
+ * 0 = g_win_eo15 / the four-step kernels).
  * Returns RMX_E_INVAL (text through rmx_last_error(NULL)) for an unknown key or a value out of range;
  * value == LONG_MIN removes a key; rmx_clear_default_options() removes all. */
 int rmx_set_default_option(const char* key, long value);
