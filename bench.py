@@ -57,6 +57,17 @@ CONFIGS = {
                       "64 windows sharded over 8 GPUs = 8 windows per GPU"),
 }
 DEFAULT_STEPS = {"cfg1": (20, 3), "cfg2": (30, 5), "cfg3": (200, 30), "cfg4": (30, 5), "cfg5": (3, 1)}
+# The reference's own capture lengths (iq_stream_client.py:459: 8192 samples; buoy_node.py:364: 16384) at its fleet size
+# (3 buoys) and at 8 buoys -- not BASELINE configs: reported beside `other_configs` as `reference_capture_lengths`, same
+# bracket, same parity check
+CAPTURE_SHAPES = {
+    "cap8192_b3": dict(B=3, N=8192, W=1024, C=1, fs=2.4e6, seed=1011, what="3 buoys, 2.4 MS/s, 1024 windows of 8192 samples (iq_stream_client.py:459)"),
+    "cap8192_b8": dict(B=8, N=8192, W=512, C=1, fs=2.4e6, seed=1012, what="8 buoys, 2.4 MS/s, 512 windows of 8192 samples"),
+    "cap16384_b3": dict(B=3, N=16384, W=512, C=1, fs=2.4e6, seed=1013, what="3 buoys, 2.4 MS/s, 512 windows of 16384 samples (buoy_node.py:364)"),
+    "cap16384_b8": dict(B=8, N=16384, W=256, C=1, fs=2.4e6, seed=1014, what="8 buoys, 2.4 MS/s, 256 windows of 16384 samples"),
+}
+CONFIGS.update(CAPTURE_SHAPES)
+DEFAULT_STEPS.update({k: (30, 5) for k in CAPTURE_SHAPES})
 
 
 def _free_port():
@@ -580,6 +591,7 @@ def job_shard(config, scaling, windows, rank, n_gpus):
 
 
 OTHER_STEPS = {"cfg1": (50, 10), "cfg2": (20, 5), "cfg4": (20, 5), "cfg5": (3, 1)}   # (timed steps, warm-up) per other shape
+OTHER_STEPS.update({k: (20, 5) for k in CAPTURE_SHAPES})
 
 
 def main():
@@ -739,6 +751,15 @@ def main():
             except Exception as e:      # a shape that fails must not take the headline line with it
                 others[name] = {"error": f"{type(e).__name__}: {e}"}
         region_order.append("other_configs (cfg1, cfg2, cfg4, cfg5: warm-up, timed steps, parity each)")
+    capture = None
+    if rank == 0 and n_gpus == 1 and args.config == "cfg3" and not args.no_other_configs:
+        capture = {}
+        for name in CAPTURE_SHAPES:
+            try:
+                capture[name] = other_config(torch, xcorr, name, dev, dev_index, sync_all, cpu_threads())
+            except Exception as e:
+                capture[name] = {"error": f"{type(e).__name__}: {e}"}
+        region_order.append("reference_capture_lengths (N = 8192 and 16384, 3 and 8 buoys: warm-up, timed steps, parity each)")
     # one-GPU projection of the 1 -> 8 GPU strong-scaling curve: the path has no collective, so G GPUs on
     # the config's job = one GPU on 1/G of its windows; timed on the resident windows of the headline shape
     projection = None
@@ -933,6 +954,7 @@ def main():
             "single_group": single,
             "strong_scaling_projection": projection,
             "other_configs": others,
+            "reference_capture_lengths": capture,
             "cpu_baseline": cpu,
             "parity": parity,
         }

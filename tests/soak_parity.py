@@ -157,6 +157,7 @@ def main():
     ap.add_argument("--device-pointers", action="store_true", help="half of the cases through RMX_IN_DEVICE | RMX_OUT_DEVICE (needs torch)")
     ap.add_argument("--caf", action="store_true", help="soak rmx_caf_batch (Doppler grid) instead of rmx_xcorr_batch")
     ap.add_argument("--detect", action="store_true", help="soak rmx_detect_batch (spectral detection) against oracle/detect_ref.py")
+    ap.add_argument("--lengths", type=int, nargs="*", default=None, help="xcorr soak: only these log2 window lengths (e.g. 14 = 16384)")
     args = ap.parse_args()
 
     import __graft_entry__ as g
@@ -179,12 +180,13 @@ def main():
     while time.time() < t_end:
         case += 1
         # window length: weight the lengths with dedicated kernels
-        logn = int(rng.choice([4, 5, 6, 7, 8, 9, 10, 11, 12, 12, 12, 13, 13, 14, 14, 15, 16, 17, 18]))
+        logn = int(rng.choice(args.lengths or [4, 5, 6, 7, 8, 9, 10, 11, 12, 12, 12, 13, 13, 14, 14, 15, 16, 17, 18]))
         N = 1 << logn
         B = int(rng.choice([2, 3, 3, 4, 5, 6, 8, 8, 9, 12, 16])) if logn <= 14 else int(rng.choice([2, 3, 4, 6, 8]))
         per_win = B * N * 8
         w_max = max(1, int(args.max_bytes // per_win))
-        W = int(min(w_max, rng.choice([1, 2, 3, 7, 16, 61, 256, 300, 1024] + ([257, 300, 517, 600, 1100] if N == 4096 else []))))
+        W = int(min(w_max, rng.choice([1, 2, 3, 7, 16, 61, 256, 300, 1024] + ([257, 300, 517, 600, 1100] if N == 4096 else []) +
+                                          ([9, 24, 33, 40, 257, 264, 520] if N == 16384 else []))))   # (N = 16384: flat / XCD-aware item order, several chunks)
         u8 = bool(rng.integers(0, 2))
         snr = float(rng.choice([10.0, 10.0, 3.0, 0.0, 20.0]))
         fs = float(rng.choice([2.4e6, 10e6, 20e6]))
@@ -205,6 +207,11 @@ def main():
         if N == 4096 and rng.integers(0, 3) == 0:
             chunk = int(rng.choice([8, 16, 104, 256, 304, 1000]))
             xcorr.set_default_option("chunk_windows", chunk)
+        # (round 5) N = 16384: a third of the cases with the quarter-transform kernels forced whatever the batch (kwin16k = 2:
+        # the flat and the XCD-aware item order on small batches) or switched off (0: g_win_eo15 / four-step, the split dispatch)
+        if N == 16384 and rng.integers(0, 3) == 0:
+            chunk = -1
+            xcorr.set_default_option("kwin16k", int(rng.choice([0, 2])))
         dev_ptr = args.device_pointers and bool(rng.integers(0, 2))
         t0 = time.time()
         eng = xcorr.XcorrEngine(B, N, W)

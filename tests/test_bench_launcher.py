@@ -158,3 +158,18 @@ def test_parse_pmc_csv_keeps_full_size_launches(tmp_path):
     got = bench.parse_pmc_csv(str(p))
     assert got == {"FETCH_SIZE": 1000.0, "launches_sampled": 3}
     assert bench.parse_pmc_csv(str(p), kernel_sub="no_such_kernel") == {}
+
+
+def test_reference_capture_shapes_are_complete_bench_shapes():
+    """`reference_capture_lengths` of the bench line: the reference's two capture lengths (iq_stream_client.py:459,
+    buoy_node.py:364) at 3 and 8 buoys -- every entry a full shape (selectable with --config, with its own step counts) whose
+    resident input stays far below one GPU's memory."""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert set(bench.CAPTURE_SHAPES) == {"cap8192_b3", "cap8192_b8", "cap16384_b3", "cap16384_b8"}
+    for name, c in bench.CAPTURE_SHAPES.items():
+        assert bench.CONFIGS[name] is c and name in bench.DEFAULT_STEPS and name in bench.OTHER_STEPS
+        assert c["N"] in (8192, 16384) and c["B"] in (3, 8) and c["C"] == 1
+        assert c["W"] * c["B"] * c["N"] * 8 < 2 ** 30
+    # the BASELINE shapes are untouched by the addition
+    assert [k for k in bench.CONFIGS if k.startswith("cfg")] == ["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"]
