@@ -12,14 +12,14 @@
 // sub-transforms across lane pairs by DPP.  The only new pieces are the ends:
 //   forward  the first radix-2 is not free here (the half is not zero-padded): slot q of thread (u, p) starts from
 //            a + (-1)^p (-i)^h b,  a = x[n], b = x[n + 4096], n = u + 256 q,  twisted by W_L^((h + 2p) n): the per-slot part
-//            W_64^((h + 2p) q) as constants, the per-thread part W_L^((h + 2p) u) inside the TW1 table of half h;
+//            W_64^((h + 2p) q) as constants, the per-thread part W_L^((h + 2p) u) as the half's one factor on top of TW1;
 //   inverse  e_h = IFFT_8192(X_j,h conj X_i,h) comes out of k_win's inverse network (same tables: the network runs on
 //            (im, re)-swapped data, so every forward factor acts as its conjugate); e_0 waits in 32 registers while e_1
 //            is computed, then r[m] = e_0 + T, r[m + 8192] = e_0 - T with T = W_L^(-m) e_1 (the twist is half 1's own
 //            sub-transform twist; lanes p = 1 hold m = n + 4096 and take the extra factor +i), |.|^2 of both, and the
 //            peak search over the thread's 32 values.
-// Per window: 2 B forward and 2 P pair transforms; the TW1 table of the other half is re-requested behind its last use, the
-// TW2 row comes from LDS (the 30 registers go to e_0).  Default pair list: k_win's schedule -- X_0 straight into the anchor
+// Per window: 2 B forward and 2 P pair transforms; TW1 = sixteen slot factors in registers (the same for both halves) times one
+// per-thread factor per half, the TW2 row comes from LDS (the 30 registers go to e_0).  Default pair list: k_win's schedule -- X_0 straight into the anchor
 // (never stored), every further X_j transformed, stored and used at once for (0, j), then the anchors 1 ... B-2 with X_j
 // streaming.  Any other pair list: all forward transforms first (an anchor run = consecutive pairs with the same first buoy).
 // Scratch per persistent workgroup: [b][half] x 64 KiB in thread-register order.
@@ -191,21 +191,19 @@ __global__ __launch_bounds__(kThreads, 2) void k_win8kl(const void* __restrict__
     __syncthreads();
 
     const int samp_bytes = U8 ? 2 : 8;
-    const __amdgpu_buffer_rsrc_t twr = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(reinterpret_cast<const char*>(tw1_g)), 0, 2 * 8 * kThreads * 16, 0x00020000);
     const int soff = t * 16;
+    // TW1 of half h = (W_4096^(u k0) 2^-6) * g_h, g_h = W_L^((h + 2p) u): the sixteen slot factors are the same for both halves and
+    // stay in the registers for the whole kernel; g_h is one complex number per thread and half.  (Round 5 first kept a full
+    // table per half and re-requested the other half's behind every use -- 64 KiB of L2 reads per transform, as much as the
+    // streamed spectrum: 8 x 512 0.513 -> 0.504 ms, 3 x 1024 0.197 -> 0.189, 16 x 256 1.000 -> 0.980 with the split.)
     float2 tw1[16];
-    // the TW1 table of half h into the twiddle registers (eight 16-byte requests; behind the last use of the other half's)
-    auto load_tw1_half = [&](int h) __attribute__((always_inline)) {
-        int bo = h * (8 * kThreads * 16);
-        asm volatile("" : "+s"(bo));
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(twr, soff, bo + j * (kThreads * 16), 0);
-            tw1[2 * j] = make_float2(__uint_as_float(w.x), __uint_as_float(w.y));
-            tw1[2 * j + 1] = make_float2(__uint_as_float(w.z), __uint_as_float(w.w));
-        }
-    };
+    load_tw1(tw1, tw1_g, t);
+    float2 g2[2];
+    {
+        const float2* gq = reinterpret_cast<const float2*>(tw1_g + 8 * kThreads);
+        g2[0] = gq[t];
+        g2[1] = gq[kThreads + t];
+    }
 
     for (int wl = blockIdx.x; wl < n_win; wl += gridDim.x) {
     C16 sa, sb;      // the two spectra of the next / current pair transform (X_i,h and X_j,h); sample buffers in phase 1
@@ -342,16 +340,11 @@ __global__ __launch_bounds__(kThreads, 2) void k_win8kl(const void* __restrict__
         });
     };
     // everything of h2 behind the role-A reads (v = the 16 values read from the image)
-    // late_tw1: request the other half's TW1 table at the END of the piece instead of behind this one's use (an A/B switch:
-    // in the interleaved first run the next buoy's samples are in flight as well; neither the spill count -- nine
-    // loop-invariant words, reloaded at four places -- nor the time improved with it)
-    auto pair_h2 = [&](auto hc, float2 (&v)[16], int out_idx, auto late_c) __attribute__((always_inline)) {
+    auto pair_h2 = [&](auto hc, float2 (&v)[16], int out_idx) __attribute__((always_inline)) {
         constexpr int h = decltype(hc)::value;
-        constexpr bool late_tw1 = decltype(late_c)::value;
         dft16_tw<false>(v, tw1);
-#ifndef K8_NO_TW1
-        if constexpr (!late_tw1) load_tw1_half(h ^ 1);   // the other half's table travels while the rest of this piece runs
-#endif
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = cmul(v[q], g2[h]);
 #ifndef K8_NO_TWIST
         twist(v, h);
 #endif
@@ -362,9 +355,6 @@ __global__ __launch_bounds__(kThreads, 2) void k_win8kl(const void* __restrict__
         if constexpr (h == 0) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) ev.set(q, v[q].x, v[q].y);
-#ifndef K8_NO_TW1
-            if constexpr (late_tw1) load_tw1_half(1);
-#endif
             return;
         } else {
 #ifdef K8_NO_PEAK
@@ -433,9 +423,6 @@ __global__ __launch_bounds__(kThreads, 2) void k_win8kl(const void* __restrict__
         }
         ++npend;
         ++npair;
-#ifndef K8_NO_TW1
-        if constexpr (late_tw1) load_tw1_half(0);
-#endif
         }
     };
     auto all_parts = [&](C16& d, int sidx) __attribute__((always_inline)) {
@@ -453,8 +440,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_win8kl(const void* __restrict__
     // ---- forward transform of half h of buoy b.  A buoy's samples arrive in pa / pb (x[n], x[n + 4096]: lane pairs ask for
     // the same sample); fold_both() turns them into the two halves' folded inputs in place, fwd_half(h) transforms one into x,
     // in registers.  `lead`: a barrier in front of the role-A stores (the transform before was a forward one too: some
-    // wave may still be at its wave-local reads; behind a pair transform its second barrier already says so).  `swap_tw1`:
-    // request the other half's TW1 table behind the use of this one (no pair transform of this half follows).  `nb`:
+    // wave may still be at its wave-local reads; behind a pair transform its second barrier already says so).  `nb`:
     // the buoy whose samples of this half are requested behind the copy into x.
     C16 pa, pb;
     // both folds of a buoy at once, in place: pa <- a + (-1)^p b (half 0), pb <- a + (-1)^p (-i) b (half 1)
@@ -469,7 +455,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_win8kl(const void* __restrict__
 #pragma unroll
         for (int q = 0; q < 16; ++q) asm volatile("" : "+v"(pa.re[q]), "+v"(pa.im[q]), "+v"(pb.re[q]), "+v"(pb.im[q]));
     };
-    auto fwd_half = [&](auto hc, float2 (&x)[16], bool lead, bool swap_tw1, int nb) __attribute__((always_inline)) {
+    auto fwd_half = [&](auto hc, float2 (&x)[16], bool lead, int nb) __attribute__((always_inline)) {
         constexpr int h = decltype(hc)::value;
 #pragma unroll
         for (int q = 0; q < 16; ++q) x[q] = h == 0 ? pa.get(q) : pb.get(q);
@@ -493,7 +479,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_win8kl(const void* __restrict__
         twist(x, h);
         dft16(x);
         mul_tw1(x, tw1);
-        if (swap_tw1) load_tw1_half(h ^ 1);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) x[q] = cmul(x[q], g2[h]);
         if (lead) __syncthreads();
         xchg_a2_write(img0, x, t);
         __syncthreads();
@@ -509,7 +496,6 @@ __global__ __launch_bounds__(kThreads, 2) void k_win8kl(const void* __restrict__
 
     load_x(pa, 0, 0);
     load_x(pb, 0, kN8 / 2);
-    load_tw1_half(0);
     int q0 = 0;                            // first pair of the generic loop below
     int ni = 0, nj = 1;                    // default list: the pair the generic loop is at
 #ifdef K8_NO_FWD
@@ -526,10 +512,10 @@ __global__ __launch_bounds__(kThreads, 2) void k_win8kl(const void* __restrict__
         cvt_x(pa);
         cvt_x(pb);
         fold_both();
-        fwd_half(std::integral_constant<int, 0>{}, x, true, true, 1);
+        fwd_half(std::integral_constant<int, 0>{}, x, true, 1);
 #pragma unroll
         for (int q = 0; q < 16; ++q) sa.set(q, x[q].x, x[q].y);
-        fwd_half(std::integral_constant<int, 1>{}, x, true, true, 1);
+        fwd_half(std::integral_constant<int, 1>{}, x, true, 1);
 #pragma unroll
         for (int j = 0; j < 8; ++j) anc[j * kThreads + t] = make_float4(x[2 * j].x, x[2 * j].y, x[2 * j + 1].x, x[2 * j + 1].y);
         for (int j = 1; j < B; ++j) {
@@ -538,7 +524,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_win8kl(const void* __restrict__
             cvt_x(pb);
             fold_both();
             // ---- half 0: X_j,0, stored for the later anchors, and e_0 of (0, j)
-            fwd_half(std::integral_constant<int, 0>{}, x, j == 1, false, j + 1 < B ? j + 1 : j);
+            fwd_half(std::integral_constant<int, 0>{}, x, j == 1, j + 1 < B ? j + 1 : j);
 #ifndef K8_NO_STORE
             store_spec(x, 2 * j);
 #endif
@@ -546,9 +532,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_win8kl(const void* __restrict__
             barrier_hook(false);
             xchg_a2_read(img0, v, t);
             __syncthreads();
-            pair_h2(std::integral_constant<int, 0>{}, v, j - 1, std::false_type{});
+            pair_h2(std::integral_constant<int, 0>{}, v, j - 1);
             // ---- half 1
-            fwd_half(std::integral_constant<int, 1>{}, x, false, false, j + 1 < B ? j + 1 : j);
+            fwd_half(std::integral_constant<int, 1>{}, x, false, j + 1 < B ? j + 1 : j);
 #ifndef K8_NO_STORE
             store_spec(x, 2 * j + 1);
 #endif
@@ -556,7 +542,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_win8kl(const void* __restrict__
             barrier_hook(false);
             xchg_a2_read(img0, v, t);
             __syncthreads();
-            pair_h2(std::integral_constant<int, 1>{}, v, j - 1, std::false_type{});
+            pair_h2(std::integral_constant<int, 1>{}, v, j - 1);
         }
         q0 = B - 1;
         nj = B - 1;                        // (the generic loop's pair counters stand at (0, B - 1))
@@ -567,11 +553,11 @@ __global__ __launch_bounds__(kThreads, 2) void k_win8kl(const void* __restrict__
             cvt_x(pa);
             cvt_x(pb);
             fold_both();
-            fwd_half(std::integral_constant<int, 0>{}, x, true, true, b + 1 < B ? b + 1 : b);
+            fwd_half(std::integral_constant<int, 0>{}, x, true, b + 1 < B ? b + 1 : b);
 #ifndef K8_NO_STORE
             store_spec(x, 2 * b);
 #endif
-            fwd_half(std::integral_constant<int, 1>{}, x, true, true, b + 1 < B ? b + 1 : b);
+            fwd_half(std::integral_constant<int, 1>{}, x, true, b + 1 < B ? b + 1 : b);
 #ifndef K8_NO_STORE
             store_spec(x, 2 * b + 1);
 #endif
@@ -615,7 +601,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_win8kl(const void* __restrict__
 #endif
             if (pend_anchor) park_anchor();     // (requested one transform ago into ev, which half 0 overwrites just below)
             pend_anchor = false;
-            pair_h2(std::integral_constant<int, 0>{}, v, q, std::false_type{});
+            pair_h2(std::integral_constant<int, 0>{}, v, q);
             pair_h1(std::integral_constant<int, 1>{}, sb, [&](auto part) __attribute__((always_inline)) {
 #ifndef K8_NO_SPEC
                 if constexpr (decltype(part)::value == 0) {
@@ -631,7 +617,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_win8kl(const void* __restrict__
 #ifndef K8_NO_B2
             __syncthreads();
 #endif
-            pair_h2(std::integral_constant<int, 1>{}, v, q, std::false_type{});
+            pair_h2(std::integral_constant<int, 1>{}, v, q);
             if (has_next) {
                 pair_h1(std::integral_constant<int, 0>{}, sb, [&](auto part) __attribute__((always_inline)) {
 #ifndef K8_NO_SPEC
@@ -652,26 +638,29 @@ __global__ __launch_bounds__(kThreads, 2) void k_win8kl(const void* __restrict__
     }   // next window of this workgroup
 }
 
-// host: TW1 of both halves ([h][8][512] float4, register order as build_tables); TW2 is k_win's table
-inline void build_tables8k(std::vector<float4>& tw1) {
+// host: TW1 of k_win8kl -- [8][512] float4: the slot factors W_4096^(u k0) 2^-6 in register order (as build_tables), then
+// [2][512] float2: the halves' per-thread factors W_16384^((h + 2p) u); TW2 is k_win's table
+inline void build_tables8kl(std::vector<float4>& tw1) {
     const double two_pi = 6.283185307179586476925286766559;
-    tw1.resize(2 * 8 * kThreads);
-    for (int h = 0; h < 2; ++h) {
-        std::vector<float2> t1(16 * kThreads);
+    tw1.assign(8 * kThreads + kThreads, make_float4(0.f, 0.f, 0.f, 0.f));
+    for (int j = 0; j < 8; ++j)
+        for (int t = 0; t < kThreads; ++t) {
+            const int u = t >> 1;
+            float w[4];
+            for (int e = 0; e < 2; ++e) {
+                const double ang = -two_pi * (double)((u * (2 * j + e)) % kM) / (double)kM;
+                w[2 * e] = (float)(std::cos(ang) * kTw1Scale);
+                w[2 * e + 1] = (float)(std::sin(ang) * kTw1Scale);
+            }
+            tw1[j * kThreads + t] = make_float4(w[0], w[1], w[2], w[3]);
+        }
+    float2* gq = reinterpret_cast<float2*>(tw1.data() + 8 * kThreads);
+    for (int h = 0; h < 2; ++h)
         for (int t = 0; t < kThreads; ++t) {
             const int p = t & 1, u = t >> 1;
-            for (int k0 = 0; k0 < 16; ++k0) {
-                // W_4096^(u k0) * W_16384^((h + 2p) u), scaled by 2^-6 like k_win's table
-                const double ang = -two_pi * (double)((u * k0) % kM) / (double)kM - two_pi * (double)((h + 2 * p) * u) / 16384.0;
-                t1[k0 * kThreads + t] = make_float2((float)(std::cos(ang) * kTw1Scale), (float)(std::sin(ang) * kTw1Scale));
-            }
+            const double ang = -two_pi * (double)((h + 2 * p) * u) / 16384.0;
+            gq[h * kThreads + t] = make_float2((float)std::cos(ang), (float)std::sin(ang));
         }
-        for (int j = 0; j < 8; ++j)
-            for (int t = 0; t < kThreads; ++t) {
-                const float2 a = t1[(2 * j) * kThreads + t], b = t1[(2 * j + 1) * kThreads + t];
-                tw1[(h * 8 + j) * kThreads + t] = make_float4(a.x, a.y, b.x, b.y);
-            }
-    }
 }
 
 }  // namespace k8

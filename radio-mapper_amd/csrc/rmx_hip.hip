@@ -1171,7 +1171,11 @@ static int generic_init(rmx_ctx* c) {
             std::vector<float4> t1_4096;
             std::vector<float2> t2;
             build_tables(t1_4096, t2);
-            k8::build_tables8k(t1);
+#ifdef RMX_EXPERIMENTS
+            if (c->knobs.get_or("kwin8k", 1) == 2) k8::build_tables8k(t1);      // (k_win8k: a full TW1 table per half)
+            else
+#endif
+            k8::build_tables8kl(t1);
             RMX_HIP(c, hipMalloc((void**)&c->g_k8_tw1, t1.size() * sizeof(float4)));
             RMX_HIP(c, hipMemcpy(c->g_k8_tw1, t1.data(), t1.size() * sizeof(float4), hipMemcpyHostToDevice));
             RMX_HIP(c, hipMalloc((void**)&c->g_k8_tw2, t2.size() * sizeof(float2)));

@@ -785,6 +785,29 @@ __global__ __launch_bounds__(kThreads, 2) void k_win8ka(const void* __restrict__
     }   // next window of this workgroup
 }
 
+// host: TW1 of k_win8k, one full table per half ([h][8][512] float4, register order as build_tables: W_4096^(u k0) W_16384^((h + 2p) u) 2^-6)
+inline void build_tables8k(std::vector<float4>& tw1) {
+    const double two_pi = 6.283185307179586476925286766559;
+    tw1.resize(2 * 8 * kThreads);
+    for (int h = 0; h < 2; ++h) {
+        std::vector<float2> t1(16 * kThreads);
+        for (int t = 0; t < kThreads; ++t) {
+            const int p = t & 1, u = t >> 1;
+            for (int k0 = 0; k0 < 16; ++k0) {
+                // W_4096^(u k0) * W_16384^((h + 2p) u), scaled by 2^-6 like k_win's table
+                const double ang = -two_pi * (double)((u * k0) % kM) / (double)kM - two_pi * (double)((h + 2 * p) * u) / 16384.0;
+                t1[k0 * kThreads + t] = make_float2((float)(std::cos(ang) * kTw1Scale), (float)(std::sin(ang) * kTw1Scale));
+            }
+        }
+        for (int j = 0; j < 8; ++j)
+            for (int t = 0; t < kThreads; ++t) {
+                const float2 a = t1[(2 * j) * kThreads + t], b = t1[(2 * j + 1) * kThreads + t];
+                tw1[(h * 8 + j) * kThreads + t] = make_float4(a.x, a.y, b.x, b.y);
+            }
+    }
+}
+
+
 // host: per-thread twiddle bases of k_win8ka ([3][512] float4: {w, w^2}, {w^4, w^8}, {c_0, c_1})
 inline void build_tables8ka(std::vector<float4>& tws) {
     const double two_pi = 6.283185307179586476925286766559;
