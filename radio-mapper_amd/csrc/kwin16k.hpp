@@ -7,8 +7,8 @@
 // points, thread t = 2u + p, three radix-16 passes, the radix-2 between the sub-transforms across lane pairs by DPP; see
 // kwin8k.hpp for the same construction at N = 8192).  Slot q of thread (u, p) of quarter h starts from
 //     [ (x0 + (-i)^h x2) + (-1)^p W_8^h (x1 + (-i)^h x3) ] W_L^((h + 4p) n),     x_r = x[n + 4096 r],  n = u + 256 q:
-// the per-thread part W_L^((h + 4p) u) sits inside quarter h's TW1 table, the per-slot part W_128^((h + 4p) q) is a row of
-// a 1 KiB LDS table.
+// the per-thread part W_L^((h + 4p) u) is one complex factor per thread and quarter on top of TW1's sixteen slot factors (the same
+// for every quarter: they stay in registers), the per-slot part W_128^((h + 4p) q) is a row of a 1 KiB LDS table.
 // The inverse of pair (i, j): e_h = IFFT_8192(X_j,h conj X_i,h) out of the inverse network, t_h[m] = W_L^(-h m) e_h[m]
 // (lanes p = 1 hold m = n + 4096 and take the extra factor W_8^(-h)), and the four quarters meet in ONE radix-4 butterfly
 //     r[m + 8192 s] = sum_h i^(h s) t_h[m]:     s = 0: a + c,  1: b + i d,  2: a - c,  3: b - i d,
@@ -27,6 +27,8 @@
 //              quarter spectra in thread-register order to spec[(w B + b) 4 + h]
 //   k16_pairs  persistent, grid = 8 S: workgroup b belongs to XCD x = b mod 8 (round-robin dispatch) and walks the items
 //              s, s + S, ... (s = b / 8) of that XCD's list [(window x, pair 0..P-1), (window x + 8, ...), ...]
+// -DK16_NO_SPEC / K16_NO_PEAK / K16_NO_SAMPLE / K16_NO_STORE: timing-only builds of the harness (results wrong);
+// -DK16_STORE_AUX=n: cache policy bits of the spectrum stores (measured: +-1 %).
 #pragma once
 #include <hip/hip_runtime.h>
 

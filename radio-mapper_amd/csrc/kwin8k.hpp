@@ -2,7 +2,7 @@
 // the fused N = 4096 kernel (kwin.hpp / fft_r16.hpp).  Round 4 built the first two versions (tools/experiments/kwin8k.hpp:
 // k_win8k without a resident anchor, k_win8ka with both anchor halves in registers: neither beat g_win_scr14); round 5's
 // third version -- ONE bin-parity half of the anchor resident in LDS, the first anchor's pairs interleaved with the forward
-// transforms -- does (8 buoys x 512 windows 0.52 against 0.73 ms, 16 x 256 1.00 against 1.42, 3 x 1024 0.21 against 0.285) and is
+// transforms -- does (8 buoys x 512 windows 0.51 against 0.73 ms, 16 x 256 1.00 against 1.42, 3 x 1024 0.19 against 0.285) and is
 // the product kernel from 5/16 of a workgroup per CU on (rmx_hip.hip: generic_batch; option kwin8k = 0: g_win_scr14).
 //
 // A window zero-padded from N = 8192 to L = 16384 splits by bin parity h into two 8192-point transforms,

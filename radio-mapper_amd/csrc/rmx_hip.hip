@@ -1164,8 +1164,8 @@ static int generic_init(rmx_ctx* c) {
         c->scratch_bytes += sbytes;
         // N = 8192: the two bin-parity halves on the fused N = 4096 kernel's network (kwin8k.hpp), same scratch size
         // (B x 2 x 64 KiB per persistent workgroup), one workgroup per CU.  Option kwin8k: 1 (default) = k_win8kl, one anchor
-        // half resident in LDS -- 0.60 against g_win_scr14's 0.73 ms at 8 buoys x 512 windows, 1.10 against 1.42 at 16 x 256,
-        // 0.27 against 0.285 at 3 x 1024 --; 0 = g_win_scr14; 2 = k_win8k (no resident anchor: -DRMX_EXPERIMENTS builds only)
+        // half resident in LDS -- 0.51 against g_win_scr14's 0.73 ms at 8 buoys x 512 windows, 1.00 against 1.42 at 16 x 256,
+        // 0.19 against 0.285 at 3 x 1024 --; 0 = g_win_scr14; 2 = k_win8k (no resident anchor: -DRMX_EXPERIMENTS builds only)
         if (c->g_logL == 14 && c->knobs.get_or("kwin8k", 1) != 0) {
             std::vector<float4> t1;
             std::vector<float4> t1_4096;
