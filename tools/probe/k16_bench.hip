@@ -3,7 +3,7 @@
 // integer lag against the generator and prints ms per batch + fraction of the 8 TB/s algorithmic roofline.
 //   build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -mllvm -simplifycfg-sink-common=false -Wno-inline-asm \
 //          -I../../radio-mapper_amd/csrc -o k16_bench k16_bench.hip
-//   run:   k16_bench [B=8] [W=256] [reps=50] [chunk=64] [pair grid per XCD S=32] [warm-up launches=20]
+//   run:   k16_bench [B=8] [W=256] [reps=50] [chunk=64] [pair grid per XCD S=32] [warm-up launches=20] [overlap: pair workgroups per XCD, 0 = off]
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -41,11 +41,12 @@ int main(int argc, char** argv) {
     int chunk = argc > 4 ? atoi(argv[4]) : 64;
     const int S = argc > 5 ? atoi(argv[5]) : 32;
     const int warm = argc > 6 ? atoi(argv[6]) : 20;      // (counter runs: 1)
+    const int Sp = argc > 7 ? atoi(argv[7]) : 0;         // > 0: pairs(c) on Sp workgroups per XCD CONCURRENTLY with fwd(c + 1) on the other CUs (two streams)
     if (chunk > W) chunk = W;
     const int N = k16::kN16, P = B * (B - 1) / 2;
     float2* iq; float4 *spec, *tw1; float2 *tw2, *tws, *gq; int* li; float *lf, *pk; k16::Pair2* prs;
     CK(hipMalloc(&iq, (size_t)W * B * N * 8));
-    CK(hipMalloc(&spec, (size_t)chunk * B * 4 * k16::kQuarterBytes));
+    CK(hipMalloc(&spec, (size_t)2 * chunk * B * 4 * k16::kQuarterBytes));      // (two chunks: the overlap mode double-buffers)
     CK(hipMalloc(&li, (size_t)W * P * 4)); CK(hipMalloc(&lf, (size_t)W * P * 4)); CK(hipMalloc(&pk, (size_t)W * P * 4));
     std::vector<float4> t1, t1_4096; std::vector<float2> t2, ts, tg;
     build_tables(t1_4096, t2);
@@ -81,6 +82,75 @@ int main(int argc, char** argv) {
                                (long)w0 * P, wc, 0, out_scale, li, lf, pk);
         }
     };
+    hipStream_t sF, sP;
+    CK(hipStreamCreateWithFlags(&sF, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&sP, hipStreamNonBlocking));
+    const int nch = (W + chunk - 1) / chunk;
+    std::vector<hipEvent_t> evF(nch), evP(nch);
+    for (int c = 0; c < nch; ++c) { CK(hipEventCreateWithFlags(&evF[c], hipEventDisableTiming)); CK(hipEventCreateWithFlags(&evP[c], hipEventDisableTiming)); }
+    hipEvent_t evDone;
+    CK(hipEventCreateWithFlags(&evDone, hipEventDisableTiming));
+    // overlap mode: fwd(0) on the whole chip; then pairs(c) on Sp workgroups per XCD beside fwd(c + 1) on the rest; the last pairs alone
+    auto launch_overlap = [&]() {
+        CK(hipStreamWaitEvent(sF, evDone, 0));                 // (the previous batch has read both buffers)
+        for (int c = 0; c < nch; ++c) {
+            const int w0 = c * chunk, wc = W - w0 < chunk ? W - w0 : chunk, items = wc * B;
+            float4* buf = spec + (size_t)(c & 1) * chunk * B * 4 * (k16::kQuarterBytes / 16);
+            if (c == 0) {
+                hipLaunchKernelGGL(k16::k16_fwd<false>, dim3(items < 256 ? items : 256), dim3(kThreads), k16::kLdsFwdBytes, sF, (const void*)iq, buf,
+                                   tw1, gq, tw2, tws, (long)w0 * B, items);
+                CK(hipEventRecord(evF[0], sF));
+            }
+            CK(hipStreamWaitEvent(sP, evF[c], 0));
+            const bool last = c + 1 == nch;
+            long per_xcd = (long)((wc + 7) / 8) * P;
+            const int sp = last ? S : Sp;
+            const int s = per_xcd < sp ? (int)per_xcd : sp;
+            hipLaunchKernelGGL(k16::k16_pairs, dim3(8 * s), dim3(kThreads), k16::kLdsPairBytes, sP, buf, tw1, gq, tw2, tws, B, prs, P,
+                               (long)w0 * P, wc, 0, out_scale, li, lf, pk);
+            CK(hipEventRecord(evP[c], sP));
+            if (!last) {
+                const int w1 = (c + 1) * chunk, wc1 = W - w1 < chunk ? W - w1 : chunk, items1 = wc1 * B;
+                float4* buf1 = spec + (size_t)((c + 1) & 1) * chunk * B * 4 * (k16::kQuarterBytes / 16);
+                if (c >= 1) CK(hipStreamWaitEvent(sF, evP[c - 1], 0));      // buffer (c + 1) & 1 was read by pairs(c - 1)
+                int nfw = 256 - 8 * Sp;
+                if (nfw > items1) nfw = items1;
+                hipLaunchKernelGGL(k16::k16_fwd<false>, dim3(nfw), dim3(kThreads), k16::kLdsFwdBytes, sF, (const void*)iq, buf1,
+                                   tw1, gq, tw2, tws, (long)w1 * B, items1);
+                CK(hipEventRecord(evF[c + 1], sF));
+            }
+        }
+        CK(hipEventRecord(evDone, sP));
+    };
+    if (Sp > 0) {
+        CK(hipEventRecord(evDone, sP));
+        CK(hipMemset(li, 0xff, (size_t)W * P * 4));
+        for (int i = 0; i < warm; ++i) launch_overlap();
+        CK(hipStreamSynchronize(sP)); CK(hipStreamSynchronize(sF));
+        CK(hipGetLastError());
+        hipEvent_t t0, t1;
+        CK(hipEventCreate(&t0)); CK(hipEventCreate(&t1));
+        CK(hipEventRecord(t0, sP));
+        CK(hipStreamWaitEvent(sF, t0, 0));
+        for (int i = 0; i < reps; ++i) launch_overlap();
+        CK(hipStreamWaitEvent(sP, evDone, 0));
+        CK(hipEventRecord(t1, sP));
+        CK(hipEventSynchronize(t1));
+        CK(hipStreamSynchronize(sF));
+        float ms; CK(hipEventElapsedTime(&ms, t0, t1));
+        ms /= reps;
+        std::vector<int> h((size_t)W * P);
+        CK(hipMemcpy(h.data(), li, h.size() * 4, hipMemcpyDeviceToHost));
+        long bad = 0;
+        for (int w = 0; w < W; ++w) {
+            int o = 0;
+            for (int i = 0; i < B; ++i)
+                for (int j = i + 1; j < B; ++j, ++o) bad += h[(size_t)w * P + o] != delay_of(w, j) - delay_of(w, i);
+        }
+        const double alg = (double)W * P * (16.0 * N + 12.0);
+        printf("[overlap] k16 B=%d W=%d chunk=%d pair workgroups per XCD %d (forward %d)  %.4f ms  frac %.4f | lags != generator %ld of %ld\n", B, W, chunk, Sp,
+               256 - 8 * Sp, ms, alg / (ms * 1e-3) / 8e12, bad, (long)W * P);
+        fflush(stdout);
+    }
     for (int round = 0; round < 2; ++round) {
         CK(hipMemset(li, 0xff, (size_t)W * P * 4));
         for (int i = 0; i < (round ? (warm < 5 ? warm : 5) : warm); ++i) launch(false);
