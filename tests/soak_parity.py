@@ -244,8 +244,11 @@ def main():
             plist = orc.pair_list(B) if pairs is None else pairs
             for w, q in zip(*np.nonzero(bad)):
                 i, j = int(plist[q, 0]), int(plist[q, 1])
-                margin, _, second = orc.peak_top2(iq[w, i], iq[w, j])
-                excused[w, q] = margin <= TOL and li[w, q] == second
+                # (the comparison above is against xcorr_batch_fast, whose own float32 transforms break an exact tie of uint8 data
+                # either way -- case 405 of the round-5 soak, seed 1001: N = 16, lags 4 and 10 tie exactly, scipy.signal.correlate
+                # and the engine say 4, the fast oracle 10 -- so the engine may hold either candidate, as in the suite's rule)
+                margin, first, second = orc.peak_top2(iq[w, i], iq[w, j])
+                excused[w, q] = margin <= TOL and li[w, q] in (first, second)
         ok = ~bad
         ref = ri + rf
         got = li + lf.astype(np.float64)

@@ -206,6 +206,27 @@ def test_exact_tie_resolves_to_lowest_index(xc):
         assert abs(lf[0, 0]) <= TOL
 
 
+def test_exact_tie_in_uint8_windows_of_16_samples(xc):
+    """Case 405 of the round-5 soak (seed 1001): 7 windows of 16 buoys x 16 raw uint8 samples at 3 dB.  In window 3 the lags 4
+    and 10 of pair (9, 13) tie EXACTLY (half-integer samples: every product sum is exact in float32): `scipy.signal.correlate`
+    -- the reference's primitive, oracle.xcorr_batch_literal -- and the engine both report the lower index, while the oracle's
+    fast form (one FFT per buoy, float32) rounds the tie the other way.  The engine must equal the literal oracle on every
+    pair-window of the batch, from raw bytes and from the decoded complex64."""
+    out = rm.synth.make_windows(7, 16, 16, 20e6, seed=539948125, snr_db=3.0, return_u8=True)
+    iq, raw = out[0], out[2]
+    ri, rf, rp = orc.xcorr_batch_literal(iq)
+    pl = orc.pair_list(16)
+    q = [k for k in range(len(pl)) if tuple(pl[k]) == (9, 13)][0]
+    margin, first, second = orc.peak_top2(iq[3, 9], iq[3, 13])
+    assert margin == 0.0 and {first, second} == {4, 10} and ri[3, q] == 4
+    with xc.XcorrEngine(16, 16, 7) as eng:
+        li, lf, pk = eng.correlate(raw)
+        lc, fc, pc = eng.correlate(iq)
+    assert np.array_equal(li, ri) and np.array_equal(lc, ri)
+    assert np.array_equal(lf, fc) and np.array_equal(pk, pc)
+    _assert_parity(li, lf, pk, ri, rf, rp)
+
+
 def test_custom_pairs_and_antisymmetry(xc):
     iq, _ = rm.synth.make_windows(16, 5, 4096, 10e6, seed=21)
     fwd = np.array([(0, 1), (0, 4), (2, 3), (1, 4)], np.int32)
